@@ -1,0 +1,154 @@
+"""L0 on-disk dataset format of the reference (reader/writer) + synthetic graphs.
+
+Format (reference writer python/utils/convert_dgl_dataset.py:99-127, reference
+reader cslicer/dataset.cpp:18-113):
+
+    <dir>/meta.txt            key=value lines: num_nodes, num_edges, feature_dim,
+                              csum_features, csum_labels, csum_offsets,
+                              csum_edges, num_classes
+    <dir>/indptr.bin          int64[N+1]
+    <dir>/indices.bin         int64[E]
+    <dir>/features.bin        float32[N*feature_dim]   (unused by the slicer)
+    <dir>/labels.bin          int32[N]                 (unused by the slicer)
+    <dir>/partition_map_opt.bin int32[N]               (loaded, ignored: the
+                              reference uses v % 4, cslicer/pyfrontend.cpp:57)
+
+The reference reader skips a final line that has no trailing newline
+(dataset.cpp:75), so the writer always terminates every line with '\n'.
+
+OGB datasets are not available offline; `synth_graph` generates graphs of the
+same shape: pareto(alpha=1.5) degrees scaled to the requested
+mean, uniform random neighbours, rows sorted, no self loops.
+"""
+import os
+
+import numpy as np
+
+PRESETS = {
+    # name: (num_nodes, mean_degree, feature_dim, num_classes)
+    "arxiv-like": (169_343, 6.9, 128, 40),
+    "products-like": (2_449_029, 50.5, 100, 47),
+    "papers-like": (111_059_956, 14.5, 128, 172),
+}
+
+
+def synth_degrees(num_nodes, mean_deg, rng, alpha=1.5, d0=1, cap=None):
+    """deg = min(floor(pareto(alpha) * s + d0), cap), s tuned so mean(deg) ~= mean_deg."""
+    if cap is None:
+        cap = int(min(num_nodes - 1, 20_000))
+    x = rng.pareto(alpha, num_nodes)
+    lo, hi = 0.0, float(max(mean_deg, 1.0)) * 64.0
+
+    def degs(s):
+        return np.minimum(np.floor(x * s + d0), cap).astype(np.int64)
+
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if degs(mid).mean() < mean_deg:
+            lo = mid
+        else:
+            hi = mid
+    return degs(0.5 * (lo + hi))
+
+
+def synth_graph(num_nodes, mean_deg, seed=0, alpha=1.5, degrees=None, sort_rows=True):
+    """Return (indptr int64[N+1], indices int64[E]) of a synthetic CSR graph."""
+    rng = np.random.default_rng(seed)
+    if degrees is None:
+        deg = synth_degrees(num_nodes, mean_deg, rng, alpha=alpha)
+    else:
+        deg = np.asarray(degrees, dtype=np.int64)
+        assert deg.shape == (num_nodes,)
+    indptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    num_edges = int(indptr[-1])
+    rows = np.repeat(np.arange(num_nodes, dtype=np.int64), deg)
+    cols = rng.integers(0, num_nodes, size=num_edges, dtype=np.int64)
+    # no self loops (convert_dgl_dataset.py:45 removes them)
+    if num_nodes > 1:
+        hit = cols == rows
+        cols[hit] = (cols[hit] + 1) % num_nodes
+    if sort_rows and num_edges:
+        # rows sorted (convert_dgl_dataset.py:47); rows are already grouped, so
+        # sorting row*N+col keeps the grouping and orders within a row.
+        key = rows * np.int64(num_nodes) + cols
+        key.sort()
+        cols = key - rows * np.int64(num_nodes)
+    return indptr, cols
+
+
+def synth_preset(name, seed=0):
+    n, d, _, _ = PRESETS[name]
+    return synth_graph(n, d, seed=seed)
+
+
+def write_l0(path, indptr, indices, features=None, labels=None, partition=None,
+             feature_dim=None, num_classes=2):
+    """Write an L0 dataset directory readable by the reference's Dataset class."""
+    os.makedirs(path, exist_ok=True)
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int64)
+    n = indptr.shape[0] - 1
+    if features is None:
+        feature_dim = 1 if feature_dim is None else feature_dim
+        features = np.zeros((n, feature_dim), dtype=np.float32)
+    features = np.ascontiguousarray(features, dtype=np.float32).reshape(n, -1)
+    if labels is None:
+        labels = np.zeros(n, dtype=np.int32)
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    if partition is None:
+        partition = (np.arange(n) % 4).astype(np.int32)
+    partition = np.ascontiguousarray(partition, dtype=np.int32)
+    indptr.tofile(os.path.join(path, "indptr.bin"))
+    indices.tofile(os.path.join(path, "indices.bin"))
+    features.tofile(os.path.join(path, "features.bin"))
+    labels.tofile(os.path.join(path, "labels.bin"))
+    partition.tofile(os.path.join(path, "partition_map_opt.bin"))
+    meta = {
+        "num_nodes": n,
+        "num_edges": int(indices.shape[0]),
+        "feature_dim": int(features.shape[1]),
+        "csum_features": int(features.sum(dtype=np.float64)),
+        "csum_labels": int(labels.sum(dtype=np.int64)),
+        "csum_offsets": int(indptr.sum(dtype=np.int64)),
+        "csum_edges": int(indices.sum(dtype=np.int64)),
+        "num_classes": int(num_classes),
+    }
+    with open(os.path.join(path, "meta.txt"), "w") as f:
+        for k, v in meta.items():
+            f.write("%s=%d\n" % (k, v))
+    return meta
+
+
+def read_meta(path):
+    meta = {}
+    with open(os.path.join(path, "meta.txt")) as f:
+        for line in f:
+            if not line.endswith("\n"):
+                break  # dataset.cpp:75: an unterminated last line is dropped
+            line = line.strip()
+            if not line:
+                continue
+            k, _, v = line.partition("=")
+            meta[k] = int(v)
+    return meta
+
+
+def read_l0(path, mmap=True, check=True):
+    """Read the graph part of an L0 directory. Returns (indptr, indices, meta)."""
+    meta = read_meta(path)
+    n, e = meta["num_nodes"], meta["num_edges"]
+    if mmap:
+        indptr = np.memmap(os.path.join(path, "indptr.bin"), dtype=np.int64, mode="r", shape=(n + 1,))
+        indices = np.memmap(os.path.join(path, "indices.bin"), dtype=np.int64, mode="r", shape=(e,))
+    else:
+        indptr = np.fromfile(os.path.join(path, "indptr.bin"), dtype=np.int64, count=n + 1)
+        indices = np.fromfile(os.path.join(path, "indices.bin"), dtype=np.int64, count=e)
+    if check:
+        # dataset.cpp:27,35 checksum asserts (compiled out in the reference's
+        # setup.py build; enforced here, loudly)
+        if int(np.sum(indptr, dtype=np.int64)) != meta["csum_offsets"]:
+            raise ValueError("indptr checksum mismatch in %s" % path)
+        if int(np.sum(indices, dtype=np.int64)) != meta["csum_edges"]:
+            raise ValueError("indices checksum mismatch in %s" % path)
+    return indptr, indices, meta
