@@ -1,0 +1,181 @@
+/* cslicer_hip.h -- C ABI of the MI355X-native cslicer engine (libcslicer_hip.so).
+ *
+ * Drop-in boundary for the reference's cslicer hot path.  The reference has no
+ * C ABI of its own: its boundary is the pybind11 module `cslicer`
+ * (cslicer/pyfrontend.cpp:116-148) over the C++ objects Slicer / Sample /
+ * BiPartite / PySample.  Each entry point below names the reference interface
+ * it stands in for.  Plain pointers and sizes only; no torch / pybind types.
+ *
+ * Execution model: the engine runs S independent "streams".  Stream s is one
+ * reference worker (one `Slicer`, WorkerPool.cpp:29-33): it owns its dedup
+ * tables and its own std::mt19937(seed) position (slicer.h:33).  One *round*
+ * slices up to S minibatches at once, batch k of the round on stream k, all in
+ * the same kernel launches.  With S = 1 the engine is the single-worker
+ * reference; with S > 1 it is the reference with S workers and the
+ * deterministic assignment "batch b -> worker b % S" (the stale
+ * cslicer/driver.cpp:69-71 deals batches the same way).
+ *
+ * Results of a round stay in device memory (result slot `slot`), in the object
+ * layout of BiPartite (bipartite.h:9-26): per layer and per list kind one
+ * int64 array holding the lists of parts 0..P-1 back to back, plus an offset
+ * table (csl_layer_meta).  csl_copy_list / csl_list_device_ptr hand them out.
+ *
+ * All functions return 0 on success, a negative CSL_E_* code on failure;
+ * csl_last_error() gives the message.  Nothing here falls back to a CPU path.
+ */
+#ifndef CSLICER_HIP_H
+#define CSLICER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSL_MAX_PARTS 8
+#define CSL_MAX_LAYERS 4
+#define CSL_ABI_VERSION 1
+
+enum {
+  CSL_OK = 0,
+  CSL_E_INVALID = -1,   /* bad argument / unsupported configuration */
+  CSL_E_HIP = -2,       /* a HIP runtime call failed */
+  CSL_E_NOMEM = -3,
+  CSL_E_STATE = -4,     /* call sequence error */
+  CSL_E_DEVICE = -5     /* the device flagged an error in a sample (see csl_sample_meta.error) */
+};
+
+/* bits of csl_sample_meta.error (set by the kernels, never silently ignored) */
+enum {
+  CSL_ERR_RNG_WINDOW = 1,     /* a draw fell outside the generated mt19937 window */
+  CSL_ERR_DUP_SEED = 2,       /* repeated seed id in one minibatch (unsupported) */
+  CSL_ERR_SEED_RANGE = 4,     /* seed id outside [0, num_nodes) */
+  CSL_ERR_FRONTIER_CAP = 8    /* a frontier outgrew its configured capacity */
+};
+
+/* list kinds: members of BiPartite (bipartite.h:9-26) */
+enum {
+  CSL_IN_NODES = 0,         /* global ids, first-occurrence order (bipartite.cpp:4) */
+  CSL_OUT_NODES = 1,        /* global ids */
+  CSL_OWNED_OUT_NODES = 2,  /* local index into out_nodes */
+  CSL_SELF_IDS_IN = 3,      /* local index into in_nodes or -1 */
+  CSL_SELF_IDS_OUT = 4,     /* local index into out_nodes or -1 */
+  CSL_TO_IDS = 5,           /* to_ids[gpu_id]  (only the own index is ever filled, slicer.cpp:41) */
+  CSL_FROM_IDS = 6,         /* from_ids[gpu_id] (slicer.cpp:42) */
+  CSL_NUM_LISTS = 7
+  /* `indptr` is len(out_nodes) ones and `indices` is empty in the reference's
+   * exported object (bipartite.h:55-66 never builds the CSR); the host binding
+   * synthesises both, they are not stored on the device. */
+};
+
+typedef struct {
+  uint32_t abi_version;      /* CSL_ABI_VERSION */
+  int32_t device;            /* HIP device ordinal */
+  /* graph: the reference's Dataset arrays (dataset.h:39-40), host memory */
+  int64_t num_nodes;
+  int64_t num_edges;
+  const int64_t* indptr;     /* [num_nodes + 1] */
+  const int64_t* indices;    /* [num_edges] */
+  const int32_t* workload;   /* [num_nodes] owner part of each node, or NULL => v % n_parts
+                                (pyfrontend.cpp:57 builds workload_map[j] = j % 4) */
+  int32_t n_parts;           /* 1..CSL_MAX_PARTS; reference: 4 (sample.h:8) */
+  int32_t n_layers;          /* 1..CSL_MAX_LAYERS; reference: 3 (slicer.cpp:75) */
+  int32_t fanout[CSL_MAX_LAYERS]; /* layer 0 = hop from the seeds; reference: 10 (slicer.cpp:10,15) */
+  int32_t max_batch;         /* largest minibatch (seeds) */
+  int32_t n_streams;         /* S, concurrent minibatches per round (reference: worker threads) */
+  int32_t n_slots;           /* result slots (rounds whose results can be alive at once), >= 1 */
+  uint32_t rng_seed;         /* reference: 5489 (default-constructed std::mt19937) */
+  uint32_t rng_ring_log2;    /* log2 of the device mt19937 window in 32-bit words (0 => 26) */
+  /* optional frontier capacity per layer input (0 => worst case batch*prod(fanout+1)) */
+  int64_t frontier_cap[CSL_MAX_LAYERS + 1];
+} csl_config;
+
+typedef struct {
+  uint32_t frontier;         /* |in| of this layer (slice_layer's `in`, slicer.cpp:25) */
+  uint32_t next_frontier;    /* |out| */
+  uint32_t draws;            /* mt19937 outputs consumed by this layer */
+  uint32_t sampled_edges;    /* neighbour_sample entries excluding the leading self entry */
+  /* list g of kind k occupies [off[k][g], off[k][g+1]) of the kind's array */
+  uint32_t off[CSL_NUM_LISTS][CSL_MAX_PARTS + 1];
+} csl_layer_meta;
+
+typedef struct {
+  uint32_t error;            /* CSL_ERR_* bits, 0 = good */
+  uint32_t n_seeds;
+  uint64_t rng_begin;        /* stream's mt19937 position before / after this sample */
+  uint64_t rng_end;
+  csl_layer_meta layer[CSL_MAX_LAYERS];
+} csl_sample_meta;
+
+typedef struct csl_engine csl_engine;
+
+const char* csl_last_error(void);
+int csl_abi_version(void);
+
+/* CSlicer::CSlicer + WorkerPool::WorkerPool + Slicer::Slicer (pyfrontend.cpp:41-70,
+ * WorkerPool.cpp:4-35, slicer.h:41-70): uploads the CSR, allocates the per-stream
+ * dedup tables (DuplicateRemover, util/duplicate.cpp:8-12) and starts the
+ * device mt19937 stream. */
+int csl_create(const csl_config* cfg, csl_engine** out);
+void csl_destroy(csl_engine* e);
+
+/* WorkerPool::training_nodes (WorkerPool.cpp:12-16,40): the epoch's node order,
+ * uploaded once; rounds then take consecutive minibatches from it. */
+int csl_set_nodes(csl_engine* e, const int64_t* host_nodes, int64_t n);
+
+/* WorkerPool::run's batch loop + Slicer::run (WorkerPool.cpp:41-50,
+ * slicer.cpp:120-140) for n_batches <= S minibatches: minibatch k =
+ * nodes[(first_batch+k)*batch : ...] goes to stream k.  Asynchronous. */
+int csl_submit_round(csl_engine* e, int64_t first_batch, int32_t batch_size, int32_t n_batches,
+                     int32_t slot);
+
+/* Slicer::get_sample(vector<long>&) (slicer.cpp:69-81) with explicit seeds:
+ * minibatch k = seeds[offsets[k] .. offsets[k+1]) (host memory). Asynchronous. */
+int csl_submit_seeds(csl_engine* e, const int64_t* seeds, const int64_t* offsets, int32_t n_batches,
+                     int32_t slot);
+
+/* blocks until every submitted round has finished (ConQueue::pop_object,
+ * util/conqueue.h:42-60, is the reference's blocking point) */
+int csl_sync(csl_engine* e);
+
+/* PySample(Sample*) (pybipartite.cpp:49-66): sizes/offsets of one sample */
+int csl_get_meta(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* out);
+
+/* PyBipartite(BiPartite*) (pybipartite.cpp:10-43): copy list `kind` of part
+ * `part` of `layer` into dst (host memory, int64).  Returns the length, or a
+ * negative error; cap = capacity of dst in elements. */
+int64_t csl_copy_list(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind,
+                      int32_t part, int64_t* dst, int64_t cap);
+
+/* zero-copy surface: device pointer of the kind's int64 array (all parts back
+ * to back, offsets in csl_layer_meta.off) */
+int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind,
+                        const int64_t** out);
+/* device pointer of the frontier entering `layer` (0..n_layers; n_layers = the
+ * nodes whose features the model reads); uint32 ids; length in meta */
+int csl_frontier_device_ptr(csl_engine* e, int32_t stream, int32_t layer, const uint32_t** out);
+int64_t csl_copy_frontier(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int64_t* dst,
+                          int64_t cap);
+
+/* HIP stream the engine launches on (a hipStream_t), for callers that order
+ * their own work after a round */
+int csl_hip_stream(csl_engine* e, void** out);
+
+/* time the dominant kernels of the last rounds with HIP events on the
+ * engine's own stream: enable, run rounds, read back per-kernel totals */
+#define CSL_NUM_KERNELS 9
+int csl_timing_enable(csl_engine* e, int32_t on);
+int csl_timing_read(csl_engine* e, double* ms_total /*[CSL_NUM_KERNELS]*/,
+                    int64_t* launches /*[CSL_NUM_KERNELS]*/);
+const char* csl_kernel_name(int32_t k);
+
+/* device mt19937 stream self-test hook: copies words [pos, pos+n) to dst */
+int csl_rng_peek(csl_engine* e, uint64_t pos, uint32_t* dst, int64_t n);
+
+/* device memory the engine holds, bytes */
+int64_t csl_device_bytes(csl_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

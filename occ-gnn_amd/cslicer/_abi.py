@@ -1,0 +1,296 @@
+"""ctypes binding of libcslicer_hip.so (include/cslicer_hip.h).
+
+The HIP library is the only implementation: if it is missing or cannot be
+loaded this module raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(HERE), "lib", "libcslicer_hip.so")
+
+MAX_PARTS = 8
+MAX_LAYERS = 4
+ABI_VERSION = 1
+NUM_LISTS = 7
+NUM_KERNELS = 9
+(IN_NODES, OUT_NODES, OWNED_OUT_NODES, SELF_IDS_IN, SELF_IDS_OUT, TO_IDS, FROM_IDS) = range(7)
+LIST_KINDS = {
+    "in_nodes": IN_NODES, "out_nodes": OUT_NODES, "owned_out_nodes": OWNED_OUT_NODES,
+    "self_ids_in": SELF_IDS_IN, "self_ids_out": SELF_IDS_OUT, "to_ids": TO_IDS, "from_ids": FROM_IDS,
+}
+ERR_BITS = {1: "RNG_WINDOW", 2: "DUP_SEED", 4: "SEED_RANGE", 8: "FRONTIER_CAP"}
+
+# every symbol include/cslicer_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "csl_last_error", "csl_abi_version", "csl_create", "csl_destroy", "csl_set_nodes",
+    "csl_submit_round", "csl_submit_seeds", "csl_sync", "csl_get_meta", "csl_copy_list",
+    "csl_list_device_ptr", "csl_frontier_device_ptr", "csl_copy_frontier", "csl_hip_stream",
+    "csl_timing_enable", "csl_timing_read", "csl_kernel_name", "csl_rng_peek", "csl_device_bytes",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("device", C.c_int32),
+        ("num_nodes", C.c_int64),
+        ("num_edges", C.c_int64),
+        ("indptr", C.POINTER(C.c_int64)),
+        ("indices", C.POINTER(C.c_int64)),
+        ("workload", C.POINTER(C.c_int32)),
+        ("n_parts", C.c_int32),
+        ("n_layers", C.c_int32),
+        ("fanout", C.c_int32 * MAX_LAYERS),
+        ("max_batch", C.c_int32),
+        ("n_streams", C.c_int32),
+        ("n_slots", C.c_int32),
+        ("rng_seed", C.c_uint32),
+        ("rng_ring_log2", C.c_uint32),
+        ("frontier_cap", C.c_int64 * (MAX_LAYERS + 1)),
+    ]
+
+
+class LayerMeta(C.Structure):
+    _fields_ = [
+        ("frontier", C.c_uint32),
+        ("next_frontier", C.c_uint32),
+        ("draws", C.c_uint32),
+        ("sampled_edges", C.c_uint32),
+        ("off", (C.c_uint32 * (MAX_PARTS + 1)) * NUM_LISTS),
+    ]
+
+
+class SampleMeta(C.Structure):
+    _fields_ = [
+        ("error", C.c_uint32),
+        ("n_seeds", C.c_uint32),
+        ("rng_begin", C.c_uint64),
+        ("rng_end", C.c_uint64),
+        ("layer", LayerMeta * MAX_LAYERS),
+    ]
+
+
+class CslError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cslicer_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libcslicer_hip.so; raises if it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `make -C occ-gnn_amd/csrc` (hipcc, gfx950). "
+            "The cslicer engine has no CPU implementation." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    p64 = C.POINTER(C.c_int64)
+    vp = C.c_void_p
+    L.csl_last_error.restype = C.c_char_p
+    L.csl_abi_version.restype = C.c_int
+    L.csl_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.csl_destroy.argtypes = [vp]
+    L.csl_destroy.restype = None
+    L.csl_set_nodes.argtypes = [vp, p64, C.c_int64]
+    L.csl_submit_round.argtypes = [vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32]
+    L.csl_submit_seeds.argtypes = [vp, p64, p64, C.c_int32, C.c_int32]
+    L.csl_sync.argtypes = [vp]
+    L.csl_get_meta.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(SampleMeta)]
+    L.csl_copy_list.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, p64, C.c_int64]
+    L.csl_copy_list.restype = C.c_int64
+    L.csl_list_device_ptr.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.csl_frontier_device_ptr.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.csl_copy_frontier.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, p64, C.c_int64]
+    L.csl_copy_frontier.restype = C.c_int64
+    L.csl_hip_stream.argtypes = [vp, C.POINTER(vp)]
+    L.csl_timing_enable.argtypes = [vp, C.c_int32]
+    L.csl_timing_read.argtypes = [vp, C.POINTER(C.c_double), p64]
+    L.csl_kernel_name.argtypes = [C.c_int32]
+    L.csl_kernel_name.restype = C.c_char_p
+    L.csl_rng_peek.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32), C.c_int64]
+    L.csl_device_bytes.argtypes = [vp]
+    L.csl_device_bytes.restype = C.c_int64
+    if L.csl_abi_version() != ABI_VERSION:
+        raise ImportError("libcslicer_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise CslError(rc, load().csl_last_error().decode())
+    return rc
+
+
+class Engine:
+    """Owns one csl_engine. Thin, argument-for-argument wrapper of the C ABI."""
+
+    def __init__(self, indptr, indices, n_parts=4, fanouts=(10, 10, 10), max_batch=1024,
+                 n_streams=1, n_slots=1, workload=None, device=0, rng_seed=5489,
+                 rng_ring_log2=0, frontier_cap=None):
+        L = load()
+        self._h = None
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int64)
+        self.workload = None if workload is None else np.ascontiguousarray(workload, dtype=np.int32)
+        self.n_parts, self.n_layers = int(n_parts), len(fanouts)
+        self.fanouts = tuple(int(f) for f in fanouts)
+        self.n_streams, self.n_slots, self.max_batch = int(n_streams), int(n_slots), int(max_batch)
+        cfg = Config()
+        cfg.abi_version = ABI_VERSION
+        cfg.device = device
+        cfg.num_nodes = self.indptr.shape[0] - 1
+        cfg.num_edges = self.indices.shape[0]
+        cfg.indptr = self.indptr.ctypes.data_as(C.POINTER(C.c_int64))
+        cfg.indices = self.indices.ctypes.data_as(C.POINTER(C.c_int64))
+        cfg.workload = (self.workload.ctypes.data_as(C.POINTER(C.c_int32))
+                        if self.workload is not None else None)
+        cfg.n_parts = self.n_parts
+        cfg.n_layers = self.n_layers
+        if self.n_layers > MAX_LAYERS:
+            raise ValueError("at most %d layers" % MAX_LAYERS)
+        for l, f in enumerate(self.fanouts):
+            cfg.fanout[l] = f
+        cfg.max_batch = self.max_batch
+        cfg.n_streams = self.n_streams
+        cfg.n_slots = self.n_slots
+        cfg.rng_seed = rng_seed
+        cfg.rng_ring_log2 = rng_ring_log2
+        if frontier_cap is not None:
+            for l, c in enumerate(frontier_cap):
+                cfg.frontier_cap[l] = int(c)
+        h = C.c_void_p()
+        _check(L.csl_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.num_nodes = int(cfg.num_nodes)
+
+    def close(self):
+        if self._h is not None:
+            load().csl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- submission
+    def set_nodes(self, nodes):
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        _check(load().csl_set_nodes(self._h, nodes.ctypes.data_as(C.POINTER(C.c_int64)), nodes.shape[0]))
+
+    def submit_round(self, first_batch, batch_size, n_batches=None, slot=0):
+        n_batches = self.n_streams if n_batches is None else n_batches
+        _check(load().csl_submit_round(self._h, first_batch, batch_size, n_batches, slot))
+
+    def submit_seeds(self, batches, slot=0):
+        flat = np.ascontiguousarray(
+            np.concatenate([np.asarray(b, dtype=np.int64).reshape(-1) for b in batches])
+            if len(batches) else np.zeros(0, dtype=np.int64))
+        offs = np.zeros(len(batches) + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in batches], out=offs[1:])
+        if flat.shape[0] == 0:
+            flat = np.zeros(1, dtype=np.int64)
+        _check(load().csl_submit_seeds(self._h, flat.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       offs.ctypes.data_as(C.POINTER(C.c_int64)), len(batches), slot))
+
+    def sync(self):
+        _check(load().csl_sync(self._h))
+
+    # -- results
+    def meta(self, stream=0, slot=0):
+        m = SampleMeta()
+        _check(load().csl_get_meta(self._h, slot, stream, C.byref(m)))
+        return m
+
+    def copy_list(self, layer, kind, part, stream=0, slot=0, meta=None):
+        m = meta if meta is not None else self.meta(stream, slot)
+        n = int(m.layer[layer].off[kind][part + 1]) - int(m.layer[layer].off[kind][part])
+        out = np.empty(max(n, 1), dtype=np.int64)
+        got = _check(load().csl_copy_list(self._h, slot, stream, layer, kind, part,
+                                          out.ctypes.data_as(C.POINTER(C.c_int64)), out.shape[0]))
+        return out[:got]
+
+    def copy_frontier(self, layer, stream=0, slot=0, meta=None):
+        m = meta if meta is not None else self.meta(stream, slot)
+        n = (m.layer[layer].frontier if layer < self.n_layers
+             else m.layer[self.n_layers - 1].next_frontier)
+        out = np.empty(max(int(n), 1), dtype=np.int64)
+        got = _check(load().csl_copy_frontier(self._h, slot, stream, layer,
+                                              out.ctypes.data_as(C.POINTER(C.c_int64)), out.shape[0]))
+        return out[:got]
+
+    def list_device_ptr(self, layer, kind, stream=0, slot=0):
+        p = C.c_void_p()
+        _check(load().csl_list_device_ptr(self._h, slot, stream, layer, kind, C.byref(p)))
+        return p.value
+
+    def frontier_device_ptr(self, layer, stream=0):
+        p = C.c_void_p()
+        _check(load().csl_frontier_device_ptr(self._h, stream, layer, C.byref(p)))
+        return p.value
+
+    def hip_stream(self):
+        p = C.c_void_p()
+        _check(load().csl_hip_stream(self._h, C.byref(p)))
+        return p.value
+
+    def sample_dict(self, stream=0, slot=0):
+        """One sample as a dict of numpy lists (the shape the parity tests compare)."""
+        m = self.meta(stream, slot)
+        out = {"layers": [], "frontier": [], "draws": [], "sampled_edges": 0}
+        for l in range(self.n_layers):
+            parts = []
+            for g in range(self.n_parts):
+                get = lambda k: self.copy_list(l, k, g, stream, slot, m)  # noqa: E731
+                bp = {
+                    "in_nodes": get(IN_NODES),
+                    "out_nodes": get(OUT_NODES),
+                    "owned_out_nodes": get(OWNED_OUT_NODES),
+                    "self_ids_in": get(SELF_IDS_IN),
+                    "self_ids_out": get(SELF_IDS_OUT),
+                    "indices": np.zeros(0, dtype=np.int64),
+                    "gpu_id": g,
+                }
+                # bipartite.h:55-66: one `1` per out_nodes push, CSR never built
+                bp["indptr"] = np.ones(bp["out_nodes"].shape[0], dtype=np.int64)
+                empty = np.zeros(0, dtype=np.int64)
+                bp["from_ids"] = [get(FROM_IDS) if j == g else empty for j in range(self.n_parts)]
+                bp["to_ids"] = [get(TO_IDS) if j == g else empty for j in range(self.n_parts)]
+                parts.append(bp)
+            out["layers"].append(parts)
+            out["draws"].append(int(m.layer[l].draws))
+            out["sampled_edges"] += int(m.layer[l].sampled_edges)
+        for l in range(self.n_layers + 1):
+            out["frontier"].append(self.copy_frontier(l, stream, slot, m))
+        out["draws_total"] = int(m.rng_end)
+        out["rng_begin"] = int(m.rng_begin)
+        return out
+
+    # -- measurement / test hooks
+    def timing_enable(self, on=True):
+        _check(load().csl_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        ms = (C.c_double * NUM_KERNELS)()
+        n = (C.c_int64 * NUM_KERNELS)()
+        _check(load().csl_timing_read(self._h, ms, n))
+        L = load()
+        return {L.csl_kernel_name(k).decode(): (float(ms[k]), int(n[k])) for k in range(NUM_KERNELS)}
+
+    def rng_peek(self, pos, n):
+        out = np.empty(n, dtype=np.uint32)
+        _check(load().csl_rng_peek(self._h, pos, out.ctypes.data_as(C.POINTER(C.c_uint32)), n))
+        return out
+
+    def device_bytes(self):
+        return int(load().csl_device_bytes(self._h))

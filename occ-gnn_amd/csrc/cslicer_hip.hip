@@ -1,0 +1,1393 @@
+// cslicer_hip.hip -- MI355X (gfx950) cslicer engine: kernels + C ABI.
+//
+// What the reference does sequentially per minibatch (cslicer/slicer.cpp:25-64,
+// bipartite.cpp:3-17, util/duplicate.cpp:14-39) is restated here as seven
+// data-parallel passes per layer over S minibatches ("streams") at once.
+// Order-dependent semantics (first-occurrence dedup, consecutive-dedup lists,
+// the single mt19937 stream) are recovered from each element's position in the
+// reference's traversal order:
+//
+//   candidate position  c = i * (fanout+1) + slot     (i = index in frontier,
+//                                                      slot 0 = the node itself)
+//   first occurrence    = smallest c                   (atomicMin into a dense
+//                                                      per-stream table, the
+//                                                      DuplicateRemover mask)
+//   stable lists        = exclusive scans of flags in c / i order
+//   rng word of (i,j)   = base + fanout * #{i' < i : deg(i') >= fanout} + j
+//
+// HBM layout (all device memory, per engine):
+//   rowinfo  u64[N]      (row offset << 24) | degree     one 8-B gather per node
+//   indices  u32[E]      CSR neighbours (ids < 2^31)
+//   wl       u8[N]       owner part (absent => v % P)
+//   rng ring u32[2^k]    mt19937 outputs, absolute position & mask
+//   per stream: entry u64[N] = {hi: index in frontier, lo: min edge position /
+//   in-node rank}; frontier / candidate / flag scratch; tile counters; result
+//   arena (int64 lists in BiPartite layout, see include/cslicer_hip.h).
+//
+// No CPU fallback exists in this file: every entry point either runs the HIP
+// kernels or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "cslicer_hip.h"
+
+namespace {
+
+constexpr uint32_t UNSET = 0xFFFFFFFFu;
+constexpr unsigned long long UNSET64 = 0xFFFFFFFFFFFFFFFFull;
+constexpr int TN = 256;  // frontier nodes per tile == threads per block
+constexpr int NW = TN / 64;
+constexpr int DEG_BITS = 24;
+constexpr uint32_t DEG_MASK = (1u << DEG_BITS) - 1;
+
+// ---- tile counter kinds -------------------------------------------------
+// kinds 0..1 are produced by k_degree, 2.. by k_sample / k_flag
+constexpr int K_NEED = 0;   // nodes with deg >= fanout (rng consumers)
+constexpr int K_EDGES = 1;  // sum of min(deg, fanout)
+constexpr int K_NEWF = 2;   // first occurrences -> next frontier
+__host__ __device__ constexpr int K_IN(int P, int g) { return 3 + g; }
+__host__ __device__ constexpr int K_OUT(int P, int g) { return 3 + P + g; }
+__host__ __device__ constexpr int K_OWNED(int P, int g) { return 3 + 2 * P + g; }
+__host__ __device__ constexpr int K_SELF(int P, int g) { return 3 + 3 * P + g; }
+__host__ __device__ constexpr int K_TO(int P, int g) { return 3 + 4 * P + g; }
+__host__ __device__ constexpr int K_FROM(int P, int g) { return 3 + 5 * P + g; }
+__host__ __device__ constexpr int NKINDS(int P) { return 3 + 6 * P; }
+constexpr int MAXK = 3 + 6 * CSL_MAX_PARTS;
+
+enum { KN_SEEDS = 0, KN_DEGREE, KN_SCAN_A, KN_SAMPLE, KN_FLAG, KN_SCAN_B, KN_EMIT, KN_FINISH, KN_MT };
+const char* const kKernelNames[CSL_NUM_KERNELS] = {"k_seeds", "k_degree", "k_scan_need", "k_sample",
+                                                   "k_flag",  "k_scan_lists", "k_emit", "k_finish",
+                                                   "k_mt19937_fill"};
+
+// Everything a layer's kernels need; passed by value.
+struct LArgs {
+  // graph
+  const unsigned long long* rowinfo;
+  const uint32_t* indices;
+  const uint8_t* wl;
+  uint32_t N, P;
+  // rng
+  const uint32_t* ring;
+  unsigned long long ring_mask, gen_lo, gen_hi;
+  unsigned long long* rngpos;   // [S] running position
+  unsigned long long* rngbase;  // [S] base of the current layer
+  // per-stream scratch (stride = elements per stream)
+  unsigned long long* entry;    // [S][N]
+  const uint32_t* fr_in;        // [S][fr_in_stride]
+  uint32_t* fr_out;             // [S][fr_out_stride]
+  size_t fr_in_stride, fr_out_stride;
+  uint32_t fr_out_cap;
+  unsigned long long* ninfo;    // [S][fcap]
+  uint32_t* hasedge;            // [S][fcap]
+  uint32_t* selfpos;            // [S][fcap]
+  size_t fcap;
+  uint32_t* cand;               // [S][ccap]
+  uint8_t* cflag;               // [S][ccap]
+  size_t ccap;
+  uint32_t* tcnt;               // [S][nk][tmax]
+  uint32_t tmax, nk;
+  uint32_t* fsize;              // [S][CSL_MAX_LAYERS+1] frontier sizes
+  csl_sample_meta* meta;        // [S] (slot already applied)
+  // result arena of this layer (slot applied): int64 [S][arena_stride]
+  long long* arena;
+  size_t arena_stride;
+  size_t list_base[CSL_NUM_LISTS];  // element offset of each kind inside a stream's arena
+  uint32_t layer, fanout, W;
+};
+
+__device__ __forceinline__ uint32_t owner(const LArgs& a, uint32_t v) {
+  return a.wl ? (uint32_t)a.wl[v] : (v % a.P);
+}
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ unsigned long long lt_mask() {
+  return (1ull << lane_id()) - 1ull;
+}
+__device__ __forceinline__ uint32_t* entry_lo(unsigned long long* e) { return reinterpret_cast<uint32_t*>(e); }
+__device__ __forceinline__ uint32_t* entry_hi(unsigned long long* e) { return reinterpret_cast<uint32_t*>(e) + 1; }
+
+// ---- k_seeds: Slicer::get_sample's copy of the batch into `in` (slicer.cpp:70-74)
+struct BatchDesc {
+  long long offset;  // into the node array
+  int count;
+  int pad;
+};
+
+__global__ __launch_bounds__(TN) void k_seeds(const long long* __restrict__ nodes, const BatchDesc* __restrict__ desc,
+                                              uint32_t* fr0, size_t fr0_stride, uint32_t* fsize,
+                                              csl_sample_meta* meta, const unsigned long long* rngpos,
+                                              uint32_t N, int n_layers) {
+  const int s = blockIdx.y;
+  const BatchDesc d = desc[s];
+  const uint32_t i = blockIdx.x * TN + threadIdx.x;
+  if (i == 0) {
+    fsize[s * (CSL_MAX_LAYERS + 1)] = (uint32_t)d.count;
+    for (int l = 1; l <= n_layers; l++) fsize[s * (CSL_MAX_LAYERS + 1) + l] = 0;
+    meta[s].error = 0;
+    meta[s].n_seeds = (uint32_t)d.count;
+    meta[s].rng_begin = rngpos[s];
+    meta[s].rng_end = rngpos[s];
+  }
+  if (i < (uint32_t)d.count) {
+    long long v = nodes[d.offset + i];
+    if (v < 0 || v >= (long long)N) {
+      atomicOr(&meta[s].error, (uint32_t)CSL_ERR_SEED_RANGE);
+      v = 0;
+    }
+    fr0[s * fr0_stride + i] = (uint32_t)v;
+  }
+}
+
+// ---- k_degree: first half of Slicer::neighbour_sample (slicer.cpp:8-9): row
+// offset and degree of every frontier node; marks the node's frontier index in
+// its dedup entry; counts rng consumers and sampled edges per tile.
+__global__ __launch_bounds__(TN) void k_degree(LArgs a) {
+  const int s = blockIdx.y;
+  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  const uint32_t tile = blockIdx.x;
+  if (tile * TN >= F) return;
+  const uint32_t i = tile * TN + threadIdx.x;
+  uint32_t need = 0, ne = 0;
+  if (i < F) {
+    const uint32_t v = a.fr_in[s * a.fr_in_stride + i];
+    const unsigned long long ri = a.rowinfo[v];
+    const uint32_t deg = (uint32_t)(ri & DEG_MASK);
+    a.ninfo[s * a.fcap + i] = ri;
+    need = deg >= a.fanout;
+    ne = deg < a.fanout ? deg : a.fanout;
+    uint32_t* hi = entry_hi(&a.entry[(size_t)s * a.N + v]);
+    if (a.layer == 0) {
+      // seeds are the only frontier that can hold repeated ids
+      if (atomicExch(hi, i) != UNSET) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
+    } else {
+      *hi = i;
+    }
+  }
+  __shared__ uint32_t s_cnt[2];
+  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t wn = __popcll(__ballot(need));
+  uint32_t we = ne;
+  for (int o = 32; o > 0; o >>= 1) we += __shfl_down(we, o);
+  if (lane_id() == 0) {
+    atomicAdd(&s_cnt[0], wn);
+    atomicAdd(&s_cnt[1], we);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) a.tcnt[((size_t)s * a.nk + threadIdx.x) * a.tmax + tile] = s_cnt[threadIdx.x];
+}
+
+// ---- k_scan: exclusive scan of tile counters kinds [k_lo, k_hi) per stream,
+// then the per-layer bookkeeping that depends on the totals.
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t x, uint32_t& total) {
+  uint32_t incl = x;
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t y = __shfl_up(incl, o);
+    if ((int)lane_id() >= o) incl += y;
+  }
+  total = __shfl(incl, 63);
+  return incl - x;
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(TN) void k_scan(LArgs a) {
+  const int s = blockIdx.x;
+  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  const uint32_t ntiles = (F + TN - 1) / TN;
+  const int k_lo = PHASE == 0 ? 0 : 2;
+  const int k_hi = PHASE == 0 ? 2 : (int)a.nk;
+  __shared__ uint32_t s_tot[MAXK];
+  const int w = threadIdx.x >> 6;
+  for (int k = k_lo + w; k < k_hi; k += NW) {
+    uint32_t* p = a.tcnt + ((size_t)s * a.nk + k) * a.tmax;
+    uint32_t run = 0;
+    for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
+      const uint32_t t = t0 + lane_id();
+      const uint32_t x = t < ntiles ? p[t] : 0;
+      uint32_t tot;
+      const uint32_t ex = wave_excl_scan(x, tot);
+      if (t < ntiles) p[t] = run + ex;
+      run += tot;
+    }
+    if (lane_id() == 0) s_tot[k] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    csl_layer_meta& m = a.meta[s].layer[a.layer];
+    if (PHASE == 0) {
+      const unsigned long long base = a.rngpos[s];
+      const unsigned long long draws = (unsigned long long)s_tot[K_NEED] * a.fanout;
+      a.rngbase[s] = base;
+      a.rngpos[s] = base + draws;
+      a.meta[s].rng_end = base + draws;
+      m.frontier = F;
+      m.draws = (uint32_t)draws;
+      m.sampled_edges = s_tot[K_EDGES];
+    } else {
+      const int P = (int)a.P;
+      uint32_t nf = s_tot[K_NEWF];
+      if (nf > a.fr_out_cap) {
+        atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_FRONTIER_CAP);
+        nf = a.fr_out_cap;
+      }
+      m.next_frontier = nf;
+      a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer + 1] = nf;
+      const int kb[CSL_NUM_LISTS] = {K_IN(P, 0),   K_OUT(P, 0), K_OWNED(P, 0), K_SELF(P, 0),
+                                     K_SELF(P, 0), K_TO(P, 0),  K_FROM(P, 0)};
+      for (int kind = 0; kind < CSL_NUM_LISTS; kind++) {
+        uint32_t run = 0;
+        for (int g = 0; g < P; g++) {
+          m.off[kind][g] = run;
+          run += s_tot[kb[kind] + g];
+        }
+        for (int g = P; g <= CSL_MAX_PARTS; g++) m.off[kind][g] = run;
+      }
+    }
+  }
+}
+
+// ---- k_sample: second half of neighbour_sample (slicer.cpp:10-21) + the
+// bookkeeping side of the slice_layer inner loop (slicer.cpp:31-44): writes the
+// candidate stream, atomicMin's each edge candidate's position into the dedup
+// entry of its source node, ORs the owner part of each sampled neighbour into
+// the node's part mask, and counts the per-node list memberships.
+__global__ __launch_bounds__(TN) void k_sample(LArgs a) {
+  const int s = blockIdx.y;
+  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  const uint32_t tile = blockIdx.x;
+  if (tile * TN >= F) return;
+  __shared__ uint32_t s_v[TN];
+  __shared__ unsigned long long s_ri[TN];
+  __shared__ uint32_t s_rng[TN];
+  __shared__ uint32_t s_hb[TN];
+  __shared__ uint32_t s_wn[NW];
+  __shared__ uint32_t s_cnt[5 * CSL_MAX_PARTS];
+  const uint32_t n = threadIdx.x;
+  const uint32_t i = tile * TN + n;
+  const uint32_t f = a.fanout, W = a.W;
+  const uint32_t P = a.P;
+  // phase 1: stage the tile's nodes, rank the rng consumers
+  uint32_t v = 0, need = 0;
+  unsigned long long ri = 0;
+  if (i < F) {
+    v = a.fr_in[s * a.fr_in_stride + i];
+    ri = a.ninfo[s * a.fcap + i];
+    need = (uint32_t)(ri & DEG_MASK) >= f;
+  }
+  const unsigned long long bm = __ballot(need);
+  if (lane_id() == 0) s_wn[n >> 6] = __popcll(bm);
+  if (n < 5 * CSL_MAX_PARTS) s_cnt[n] = 0;
+  s_v[n] = v;
+  s_ri[n] = ri;
+  s_hb[n] = 0;
+  __syncthreads();
+  {
+    uint32_t r = __popcll(bm & lt_mask());
+    for (uint32_t w = 0; w < (n >> 6); w++) r += s_wn[w];
+    const uint32_t tb = a.tcnt[((size_t)s * a.nk + K_NEED) * a.tmax + tile];
+    s_rng[n] = need ? (tb + r) * f : UNSET;
+  }
+  __syncthreads();
+  // phase 2: one candidate per thread per iteration, coalesced over c
+  const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
+  const uint32_t ncand = nodes_here * W;
+  const unsigned long long rbase = a.rngbase[s];
+  unsigned long long* ent = a.entry + (size_t)s * a.N;
+  uint32_t* cand = a.cand + (size_t)s * a.ccap + (size_t)tile * TN * W;
+  for (uint32_t k = n; k < ncand; k += TN) {
+    const uint32_t nn = k / W;
+    const uint32_t slot = k - nn * W;
+    const uint32_t vv = s_v[nn];
+    uint32_t val;
+    if (slot == 0) {
+      val = vv;
+    } else {
+      const unsigned long long r2 = s_ri[nn];
+      const uint32_t deg = (uint32_t)(r2 & DEG_MASK);
+      const unsigned long long off = r2 >> DEG_BITS;
+      const uint32_t j = slot - 1;
+      if (deg < f) {
+        val = j < deg ? a.indices[off + j] : UNSET;
+      } else {
+        const unsigned long long pos = rbase + s_rng[nn] + j;
+        uint32_t rnd = 0;
+        if (pos >= a.gen_lo && pos < a.gen_hi) {
+          rnd = a.ring[pos & a.ring_mask];
+        } else {
+          atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_RNG_WINDOW);
+        }
+        val = a.indices[off + (rnd % deg)];
+      }
+      if (val != UNSET && val != vv) {
+        const uint32_t c = (tile * TN) * W + k;
+        atomicMin(entry_lo(&ent[val]), c);
+        atomicOr(&s_hb[nn], 1u << owner(a, val));
+      }
+    }
+    cand[k] = val;
+  }
+  __syncthreads();
+  // phase 3: per-node list memberships (bipartite.h:33-66 push conditions)
+  uint32_t hb = 0, to = 0;
+  const bool act = i < F;
+  if (act) {
+    hb = s_hb[n];
+    to = owner(a, v);
+    a.hasedge[s * a.fcap + i] = hb;
+  }
+  for (uint32_t g = 0; g < P; g++) {
+    const bool own = act && to == g;
+    const bool has = act && ((hb >> g) & 1u);
+    const uint32_t c_out = __popcll(__ballot(has));
+    const uint32_t c_owned = __popcll(__ballot(own && has));
+    const uint32_t c_self = __popcll(__ballot(own));
+    const uint32_t c_to = __popcll(__ballot(own && (hb & ~(1u << g)) != 0));
+    const uint32_t c_from = __popcll(__ballot(has && !own));
+    if (lane_id() == 0) {
+      if (c_out) atomicAdd(&s_cnt[0 * CSL_MAX_PARTS + g], c_out);
+      if (c_owned) atomicAdd(&s_cnt[1 * CSL_MAX_PARTS + g], c_owned);
+      if (c_self) atomicAdd(&s_cnt[2 * CSL_MAX_PARTS + g], c_self);
+      if (c_to) atomicAdd(&s_cnt[3 * CSL_MAX_PARTS + g], c_to);
+      if (c_from) atomicAdd(&s_cnt[4 * CSL_MAX_PARTS + g], c_from);
+    }
+  }
+  __syncthreads();
+  if (n < 5 * P) {
+    const uint32_t kind5 = n / P, g = n - kind5 * P;
+    a.tcnt[((size_t)s * a.nk + (K_OUT(P, 0) + kind5 * P + g)) * a.tmax + tile] = s_cnt[kind5 * CSL_MAX_PARTS + g];
+  }
+}
+
+// ---- k_flag: decides, for every candidate, whether it is the first
+// occurrence of its node (a) in the next frontier (out_dr mask, slicer.cpp:45-49)
+// and (b) among the in_nodes of its slice (order_and_remove_duplicates,
+// bipartite.cpp:4).  Runs after every atomicMin of k_sample has landed.
+// flag byte: bit0 new-frontier, bit1 first-in-node, bits2-4 owner part.
+__global__ __launch_bounds__(TN) void k_flag(LArgs a) {
+  const int s = blockIdx.y;
+  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  const uint32_t tile = blockIdx.x;
+  if (tile * TN >= F) return;
+  __shared__ uint32_t s_v[TN];
+  __shared__ uint32_t s_cnt[1 + CSL_MAX_PARTS];
+  const uint32_t n = threadIdx.x;
+  const uint32_t W = a.W, P = a.P;
+  {
+    const uint32_t i = tile * TN + n;
+    s_v[n] = i < F ? a.fr_in[s * a.fr_in_stride + i] : 0;
+    if (n < 1 + CSL_MAX_PARTS) s_cnt[n] = 0;
+  }
+  __syncthreads();
+  const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
+  const uint32_t ncand = nodes_here * W;
+  const uint32_t iters = (ncand + TN - 1) / TN;
+  const unsigned long long* ent = a.entry + (size_t)s * a.N;
+  const size_t cbase = (size_t)s * a.ccap + (size_t)tile * TN * W;
+  for (uint32_t it = 0; it < iters; it++) {
+    const uint32_t k = it * TN + n;
+    uint32_t newf = 0, fe = 0, g = 0;
+    if (k < ncand) {
+      const uint32_t nn = k / W;
+      const uint32_t slot = k - nn * W;
+      const uint32_t val = a.cand[cbase + k];
+      if (val != UNSET) {
+        const uint32_t c = (tile * TN) * W + k;
+        const unsigned long long e = ent[val];
+        const uint32_t epos = (uint32_t)e, self = (uint32_t)(e >> 32);
+        g = owner(a, val);
+        if (slot == 0) {
+          newf = epos > c;  // UNSET compares greater than any position
+        } else if (val != s_v[nn]) {
+          fe = epos == c;
+          newf = fe && (self == UNSET || (unsigned long long)self * W > c);
+        }
+      }
+      a.cflag[cbase + k] = (uint8_t)(newf | (fe << 1) | (g << 2));
+    }
+    const uint32_t c0 = __popcll(__ballot(newf));
+    if (lane_id() == 0 && c0) atomicAdd(&s_cnt[0], c0);
+    for (uint32_t gg = 0; gg < P; gg++) {
+      const uint32_t cg = __popcll(__ballot(fe && g == gg));
+      if (lane_id() == 0 && cg) atomicAdd(&s_cnt[1 + gg], cg);
+    }
+  }
+  __syncthreads();
+  if (n < 1 + P) a.tcnt[((size_t)s * a.nk + (K_NEWF + n)) * a.tmax + tile] = s_cnt[n];
+}
+
+// ---- k_emit: stable compaction of everything into the BiPartite lists
+// (bipartite.h:9-26) and of the next frontier.  Positions come from the tile
+// scans (k_scan) plus ballot ranks inside the tile, so every list is in the
+// reference's push order.
+__global__ __launch_bounds__(TN) void k_emit(LArgs a) {
+  const int s = blockIdx.y;
+  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  const uint32_t tile = blockIdx.x;
+  if (tile * TN >= F) return;
+  const uint32_t n = threadIdx.x, w = n >> 6;
+  const uint32_t W = a.W, P = a.P;
+  const csl_layer_meta& m = a.meta[s].layer[a.layer];
+  long long* ar = a.arena + (size_t)s * a.arena_stride;
+  const uint32_t* tc = a.tcnt + (size_t)s * a.nk * a.tmax;
+#define TB(kind) tc[(size_t)(kind)*a.tmax + tile]
+  __shared__ uint32_t s_wc[2][NW][1 + CSL_MAX_PARTS];
+  __shared__ uint32_t s_run[1 + CSL_MAX_PARTS];
+  __shared__ uint32_t s_wn[NW][5 * CSL_MAX_PARTS];
+  if (n < 1 + CSL_MAX_PARTS) s_run[n] = 0;
+  // ---- candidate-level lists: next frontier, in_nodes
+  const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
+  const uint32_t ncand = nodes_here * W;
+  const uint32_t iters = (ncand + TN - 1) / TN;
+  const size_t cbase = (size_t)s * a.ccap + (size_t)tile * TN * W;
+  unsigned long long* ent = a.entry + (size_t)s * a.N;
+  const uint32_t nf_cap = m.next_frontier;  // already clamped to capacity
+  for (uint32_t it = 0; it < iters; it++) {
+    const uint32_t k = it * TN + n;
+    uint32_t newf = 0, fe = 0, g = 0, val = 0;
+    if (k < ncand) {
+      const uint32_t fl = a.cflag[cbase + k];
+      newf = fl & 1u;
+      fe = (fl >> 1) & 1u;
+      g = fl >> 2;
+      if (fl & 3u) val = a.cand[cbase + k];
+    }
+    const uint32_t b = it & 1;
+    const unsigned long long m0 = __ballot(newf);
+    const uint32_t r0 = __popcll(m0 & lt_mask());
+    if (lane_id() == 0) s_wc[b][w][0] = __popcll(m0);
+    uint32_t rE = 0;
+    for (uint32_t gg = 0; gg < P; gg++) {
+      const unsigned long long mg = __ballot(fe && g == gg);
+      if (fe && g == gg) rE = __popcll(mg & lt_mask());
+      if (lane_id() == 0) s_wc[b][w][1 + gg] = __popcll(mg);
+    }
+    __syncthreads();
+    if (newf) {
+      uint32_t p = s_run[0] + r0;
+      for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][0];
+      p += TB(K_NEWF);
+      if (p < nf_cap) a.fr_out[s * a.fr_out_stride + p] = val;
+    }
+    if (fe) {
+      uint32_t p = s_run[1 + g] + rE;
+      for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][1 + g];
+      p += TB(K_IN(P, g));  // local index inside slice g's in_nodes
+      ar[a.list_base[CSL_IN_NODES] + m.off[CSL_IN_NODES][g] + p] = (long long)val;
+      *entry_lo(&ent[val]) = p;  // DuplicateRemover::replace's lookup value (mask[v]-1)
+    }
+    __syncthreads();
+    if (n < 1 + P) {
+      uint32_t t = 0;
+      for (uint32_t ww = 0; ww < NW; ww++) t += s_wc[b][ww][n];
+      s_run[n] += t;
+    }
+  }
+  // ---- node-level lists: out_nodes, owned_out_nodes, self_ids_out, to_ids, from_ids
+  const uint32_t i = tile * TN + n;
+  const bool act = i < F;
+  uint32_t v = 0, hb = 0, to = 0;
+  if (act) {
+    v = a.fr_in[s * a.fr_in_stride + i];
+    hb = a.hasedge[s * a.fcap + i];
+    to = owner(a, v);
+  }
+  uint32_t r_out[CSL_MAX_PARTS];
+  uint32_t r_owned = 0, r_self = 0, r_to = 0, r_from[CSL_MAX_PARTS];
+#pragma unroll
+  for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
+    r_out[g] = 0;
+    r_from[g] = 0;
+    if (g < P) {
+      const bool own = act && to == g;
+      const bool has = act && ((hb >> g) & 1u);
+      const unsigned long long b_out = __ballot(has);
+      const unsigned long long b_owned = __ballot(own && has);
+      const unsigned long long b_self = __ballot(own);
+      const unsigned long long b_to = __ballot(own && (hb & ~(1u << g)) != 0);
+      const unsigned long long b_from = __ballot(has && !own);
+      const unsigned long long lt = lt_mask();
+      r_out[g] = __popcll(b_out & lt);
+      r_from[g] = __popcll(b_from & lt);
+      if (own) {
+        r_owned = __popcll(b_owned & lt);
+        r_self = __popcll(b_self & lt);
+        r_to = __popcll(b_to & lt);
+      }
+      if (lane_id() == 0) {
+        s_wn[w][0 * CSL_MAX_PARTS + g] = __popcll(b_out);
+        s_wn[w][1 * CSL_MAX_PARTS + g] = __popcll(b_owned);
+        s_wn[w][2 * CSL_MAX_PARTS + g] = __popcll(b_self);
+        s_wn[w][3 * CSL_MAX_PARTS + g] = __popcll(b_to);
+        s_wn[w][4 * CSL_MAX_PARTS + g] = __popcll(b_from);
+      }
+    }
+  }
+  __syncthreads();
+  if (act) {
+    long long outrank_to = -1;
+#pragma unroll
+    for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
+      if (g < P && ((hb >> g) & 1u)) {
+        uint32_t p = r_out[g];
+        for (uint32_t ww = 0; ww < w; ww++) p += s_wn[ww][0 * CSL_MAX_PARTS + g];
+        p += TB(K_OUT(P, g));  // local index inside slice g's out_nodes
+        ar[a.list_base[CSL_OUT_NODES] + m.off[CSL_OUT_NODES][g] + p] = (long long)v;
+        if (g == to) {
+          outrank_to = p;
+        } else {
+          uint32_t q = r_from[g];
+          for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][4 * CSL_MAX_PARTS + g];
+          q += TB(K_FROM(P, g));
+          ar[a.list_base[CSL_FROM_IDS] + m.off[CSL_FROM_IDS][g] + q] = (long long)p;
+        }
+      }
+    }
+    {
+      uint32_t q = r_self;
+      for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][2 * CSL_MAX_PARTS + to];
+      q += TB(K_SELF(P, to));
+      const uint32_t pos = m.off[CSL_SELF_IDS_OUT][to] + q;
+      ar[a.list_base[CSL_SELF_IDS_OUT] + pos] = outrank_to;
+      a.selfpos[s * a.fcap + i] = pos;  // k_finish fills self_ids_in at the same place
+    }
+    if (outrank_to >= 0) {
+      uint32_t q = r_owned;
+      for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][1 * CSL_MAX_PARTS + to];
+      q += TB(K_OWNED(P, to));
+      ar[a.list_base[CSL_OWNED_OUT_NODES] + m.off[CSL_OWNED_OUT_NODES][to] + q] = outrank_to;
+    }
+    if ((hb & ~(1u << to)) != 0) {
+      uint32_t q = r_to;
+      for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][3 * CSL_MAX_PARTS + to];
+      q += TB(K_TO(P, to));
+      ar[a.list_base[CSL_TO_IDS] + m.off[CSL_TO_IDS][to] + q] = outrank_to;
+    }
+  }
+#undef TB
+}
+
+// ---- k_finish: self_ids_in (replace(self_ids_in), bipartite.cpp:6) and
+// DuplicateRemover::clear (util/duplicate.cpp:28-33).  Every touched entry
+// belongs to exactly one node of the next frontier, which owns its reset.
+__global__ __launch_bounds__(TN) void k_finish(LArgs a) {
+  const int s = blockIdx.y;
+  const uint32_t Fn = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer + 1];
+  const uint32_t j = blockIdx.x * TN + threadIdx.x;
+  if (j >= Fn) return;
+  const uint32_t v = a.fr_out[s * a.fr_out_stride + j];
+  unsigned long long* ep = &a.entry[(size_t)s * a.N + v];
+  const unsigned long long e = *ep;
+  const uint32_t epos = (uint32_t)e, self = (uint32_t)(e >> 32);
+  if (self != UNSET) {
+    long long* ar = a.arena + (size_t)s * a.arena_stride;
+    ar[a.list_base[CSL_SELF_IDS_IN] + a.selfpos[s * a.fcap + self]] = epos == UNSET ? -1ll : (long long)epos;
+  }
+  *ep = UNSET64;
+}
+
+// ---- k_mt19937_fill: the std::mt19937 stream (slicer.h:33), generated on the
+// device into a ring.  One workgroup; the 624-word twist splits into three
+// dependent phases of independent words (i+397 wraps at 227).
+__device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t l) {
+  const uint32_t y = (u & 0x80000000u) | (l & 0x7fffffffu);
+  return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__global__ __launch_bounds__(TN) void k_mt19937_fill(uint32_t* state, uint32_t* ring, unsigned long long ring_mask,
+                                                    unsigned long long pos0, uint32_t nblocks) {
+  __shared__ uint32_t buf[2][624];
+  const uint32_t t = threadIdx.x;
+  for (uint32_t i = t; i < 624; i += TN) buf[0][i] = state[i];
+  __syncthreads();
+  uint32_t cur = 0;
+  for (uint32_t blk = 0; blk < nblocks; blk++) {
+    const uint32_t* A = buf[cur];
+    uint32_t* B = buf[cur ^ 1];
+    if (t < 227) B[t] = A[t + 397] ^ mt_twist(A[t], A[t + 1]);
+    __syncthreads();
+    if (t < 227) B[227 + t] = B[t] ^ mt_twist(A[227 + t], A[228 + t]);
+    __syncthreads();
+    if (t < 169) B[454 + t] = B[227 + t] ^ mt_twist(A[454 + t], A[455 + t]);
+    if (t == 255) B[623] = B[396] ^ mt_twist(A[623], B[0]);
+    __syncthreads();
+    const unsigned long long base = pos0 + (unsigned long long)blk * 624ull;
+    for (uint32_t i = t; i < 624; i += TN) {
+      uint32_t y = B[i];
+      y ^= y >> 11;
+      y ^= (y << 7) & 0x9d2c5680u;
+      y ^= (y << 15) & 0xefc60000u;
+      y ^= y >> 18;
+      ring[(base + i) & ring_mask] = y;
+    }
+    cur ^= 1;
+  }
+  __syncthreads();
+  for (uint32_t i = t; i < 624; i += TN) state[i] = buf[cur][i];
+}
+
+// fills u64 words with all ones
+__global__ void k_fill64(unsigned long long* p, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = UNSET64;
+}
+
+// packs the reference's int64 CSR into rowinfo / u32 indices on the device
+__global__ void k_pack_rows(const long long* indptr, unsigned long long* rowinfo, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const unsigned long long o = (unsigned long long)indptr[i];
+    const unsigned long long d = (unsigned long long)(indptr[i + 1] - indptr[i]);
+    rowinfo[i] = (o << DEG_BITS) | d;
+  }
+}
+__global__ void k_pack_indices(const long long* src, uint32_t* dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = (uint32_t)src[i];
+}
+__global__ void k_pack_wl(const int* src, uint8_t* dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = (uint8_t)src[i];
+}
+
+// ------------------------------------------------------------------ host side
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHECK(x)                                                                          \
+  do {                                                                                       \
+    hipError_t _e = (x);                                                                     \
+    if (_e != hipSuccess)                                                                    \
+      return fail(CSL_E_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+struct TimedEvent {
+  hipEvent_t a, b;
+  int kernel;
+};
+
+}  // namespace
+
+struct csl_engine {
+  csl_config cfg;
+  int S, P, L, slots;
+  uint32_t N;
+  size_t E;
+  hipStream_t stream = nullptr, rng_stream = nullptr;
+  hipEvent_t rng_event = nullptr;
+  // graph
+  unsigned long long* rowinfo = nullptr;
+  uint32_t* indices = nullptr;
+  uint8_t* wl = nullptr;
+  // node order
+  long long* nodes = nullptr;
+  int64_t n_nodes = 0;
+  long long* seedbuf = nullptr;  // staging for csl_submit_seeds
+  size_t seedbuf_cap = 0;
+  // rng
+  uint32_t* ring = nullptr;
+  uint32_t* mt_state = nullptr;
+  uint64_t ring_words = 0, gen_hi = 0;
+  unsigned long long* rngpos = nullptr;
+  unsigned long long* rngbase = nullptr;
+  std::vector<uint64_t> pos_ub, pos_lb;
+  uint64_t worst_draws = 0;
+  // capacities
+  size_t fcap[CSL_MAX_LAYERS + 1];  // frontier capacity entering layer l
+  size_t fcap_max = 0, ccap_max = 0;
+  uint32_t tmax = 0, nk = 0;
+  // scratch
+  unsigned long long* entry = nullptr;
+  uint32_t* fr[CSL_MAX_LAYERS + 1] = {};
+  unsigned long long* ninfo = nullptr;
+  uint32_t* hasedge = nullptr;
+  uint32_t* selfpos = nullptr;
+  uint32_t* cand = nullptr;
+  uint8_t* cflag = nullptr;
+  uint32_t* tcnt = nullptr;
+  uint32_t* fsize = nullptr;
+  // results
+  csl_sample_meta* meta = nullptr;  // [slots][S]
+  long long* arena[CSL_MAX_LAYERS] = {};  // [slots][S][arena_stride[l]]
+  size_t arena_stride[CSL_MAX_LAYERS];
+  size_t list_base[CSL_MAX_LAYERS][CSL_NUM_LISTS];
+  size_t list_cap[CSL_MAX_LAYERS][CSL_NUM_LISTS];
+  // batch descriptors
+  BatchDesc* desc_dev = nullptr;   // [slots][S]
+  BatchDesc* desc_host = nullptr;  // pinned, [slots][S]
+  // host mirror of meta for fetches
+  std::vector<csl_sample_meta> meta_host;
+  std::vector<char> meta_valid;  // per slot
+  int64_t dev_bytes = 0;
+  bool dirty = false;  // work submitted since last sync
+  // timing
+  bool timing = false;
+  std::vector<TimedEvent> timed;
+  std::vector<hipEvent_t> event_pool;
+  double t_ms[CSL_NUM_KERNELS] = {};
+  int64_t t_n[CSL_NUM_KERNELS] = {};
+};
+
+namespace {
+
+template <typename T>
+int dmalloc(csl_engine* e, T** p, size_t count) {
+  size_t bytes = count * sizeof(T);
+  if (bytes == 0) bytes = sizeof(T);
+  hipError_t r = hipMalloc((void**)p, bytes);
+  if (r != hipSuccess) return fail(CSL_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(r));
+  e->dev_bytes += (int64_t)bytes;
+  return 0;
+}
+#define DMALLOC(p, n)                      \
+  do {                                     \
+    int _r = dmalloc(e, &(p), (n));        \
+    if (_r) return _r;                     \
+  } while (0)
+
+hipEvent_t get_event(csl_engine* e) {
+  if (!e->event_pool.empty()) {
+    hipEvent_t ev = e->event_pool.back();
+    e->event_pool.pop_back();
+    return ev;
+  }
+  hipEvent_t ev;
+  hipEventCreate(&ev);
+  return ev;
+}
+
+struct Timed {
+  csl_engine* e;
+  TimedEvent te;
+  bool on;
+  Timed(csl_engine* e_, int kernel, hipStream_t st) : e(e_), on(e_->timing) {
+    if (on) {
+      te.kernel = kernel;
+      te.a = get_event(e);
+      te.b = get_event(e);
+      hipEventRecord(te.a, st);
+      stream = st;
+    }
+  }
+  hipStream_t stream = nullptr;
+  ~Timed() {
+    if (on) {
+      hipEventRecord(te.b, stream);
+      e->timed.push_back(te);
+    }
+  }
+};
+
+int collect_timing(csl_engine* e) {
+  for (auto& te : e->timed) {
+    float ms = 0.f;
+    HIPCHECK(hipEventSynchronize(te.b));
+    HIPCHECK(hipEventElapsedTime(&ms, te.a, te.b));
+    e->t_ms[te.kernel] += ms;
+    e->t_n[te.kernel] += 1;
+    e->event_pool.push_back(te.a);
+    e->event_pool.push_back(te.b);
+  }
+  e->timed.clear();
+  return 0;
+}
+
+// host init of the mt19937 state (ISO C++ [rand.eng.mers] seeding)
+void mt_seed_host(uint32_t seed, uint32_t* mt) {
+  mt[0] = seed;
+  for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+}
+
+int refresh_positions(csl_engine* e) {
+  // exact stream positions; only valid when the device is idle
+  std::vector<unsigned long long> tmp(e->S);
+  HIPCHECK(hipMemcpy(tmp.data(), e->rngpos, sizeof(unsigned long long) * e->S, hipMemcpyDeviceToHost));
+  for (int s = 0; s < e->S; s++) e->pos_ub[s] = e->pos_lb[s] = tmp[s];
+  return 0;
+}
+
+// make sure the ring holds [min lower bound, max upper bound + one round)
+int ensure_rng(csl_engine* e) {
+  uint64_t need_hi = 0, lo = UINT64_MAX;
+  for (int s = 0; s < e->S; s++) {
+    if (e->pos_ub[s] + e->worst_draws > need_hi) need_hi = e->pos_ub[s] + e->worst_draws;
+    if (e->pos_lb[s] < lo) lo = e->pos_lb[s];
+  }
+  if (need_hi <= e->gen_hi) return 0;
+  // generate ahead: half a ring beyond the need, as far as the ring allows
+  uint64_t target = need_hi + e->ring_words / 2;
+  if (target > lo + e->ring_words) {
+    // upper bounds drift above the real positions; resync before giving up
+    if (e->dirty) {
+      HIPCHECK(hipStreamSynchronize(e->stream));
+      e->dirty = false;
+      int r = collect_timing(e);
+      if (r) return r;
+    }
+    int r = refresh_positions(e);
+    if (r) return r;
+    need_hi = 0;
+    lo = UINT64_MAX;
+    for (int s = 0; s < e->S; s++) {
+      if (e->pos_ub[s] + e->worst_draws > need_hi) need_hi = e->pos_ub[s] + e->worst_draws;
+      if (e->pos_lb[s] < lo) lo = e->pos_lb[s];
+    }
+    if (need_hi <= e->gen_hi) return 0;
+    target = need_hi + e->ring_words / 2;
+    if (target > lo + e->ring_words) target = lo + e->ring_words;
+    if (target < need_hi)
+      return fail(CSL_E_INVALID, "mt19937 ring too small: streams span %llu words, ring %llu (raise rng_ring_log2)",
+                  (unsigned long long)(need_hi - lo), (unsigned long long)e->ring_words);
+  }
+  const uint64_t words = target - e->gen_hi;
+  const uint32_t nblocks = (uint32_t)(words / 624);  // round down: never overwrite below `lo`
+  if (nblocks == 0) return fail(CSL_E_INVALID, "mt19937 ring too small for one round");
+  {
+    Timed t(e, KN_MT, e->rng_stream);
+    hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(TN), 0, e->rng_stream, e->mt_state, e->ring,
+                       (unsigned long long)(e->ring_words - 1), (unsigned long long)e->gen_hi, nblocks);
+  }
+  HIPCHECK(hipGetLastError());
+  e->gen_hi += (uint64_t)nblocks * 624ull;
+  if (e->gen_hi < need_hi) return fail(CSL_E_INVALID, "mt19937 ring too small for one round");
+  HIPCHECK(hipEventRecord(e->rng_event, e->rng_stream));
+  HIPCHECK(hipStreamWaitEvent(e->stream, e->rng_event, 0));
+  return 0;
+}
+
+int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int32_t slot) {
+  const int S = e->S, L = e->L;
+  int r = ensure_rng(e);
+  if (r) return r;
+  // the generator may only overwrite ring words below every stream's position
+  const unsigned long long gen_lo = e->gen_hi > e->ring_words ? e->gen_hi - e->ring_words : 0;
+  BatchDesc* dd = e->desc_dev + (size_t)slot * S;
+  HIPCHECK(hipMemcpyAsync(dd, e->desc_host + (size_t)slot * S, sizeof(BatchDesc) * S, hipMemcpyHostToDevice,
+                          e->stream));
+  csl_sample_meta* meta = e->meta + (size_t)slot * S;
+  {
+    Timed t(e, KN_SEEDS, e->stream);
+    dim3 grid((unsigned)((e->fcap[0] + TN - 1) / TN), S);
+    hipLaunchKernelGGL(k_seeds, grid, dim3(TN), 0, e->stream, nodes_dev, dd, e->fr[0], e->fcap[0], e->fsize, meta,
+                       e->rngpos, e->N, L);
+  }
+  for (int l = 0; l < L; l++) {
+    LArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rowinfo = e->rowinfo;
+    a.indices = e->indices;
+    a.wl = e->wl;
+    a.N = e->N;
+    a.P = (uint32_t)e->P;
+    a.ring = e->ring;
+    a.ring_mask = e->ring_words - 1;
+    a.gen_lo = gen_lo;
+    a.gen_hi = e->gen_hi;
+    a.rngpos = e->rngpos;
+    a.rngbase = e->rngbase;
+    a.entry = e->entry;
+    a.fr_in = e->fr[l];
+    a.fr_out = e->fr[l + 1];
+    a.fr_in_stride = e->fcap[l];
+    a.fr_out_stride = e->fcap[l + 1];
+    a.fr_out_cap = (uint32_t)e->fcap[l + 1];
+    a.ninfo = e->ninfo;
+    a.hasedge = e->hasedge;
+    a.selfpos = e->selfpos;
+    a.fcap = e->fcap_max;
+    a.cand = e->cand;
+    a.cflag = e->cflag;
+    a.ccap = e->ccap_max;
+    a.tcnt = e->tcnt;
+    a.tmax = e->tmax;
+    a.nk = e->nk;
+    a.fsize = e->fsize;
+    a.meta = meta;
+    a.arena = e->arena[l] + (size_t)slot * S * e->arena_stride[l];
+    a.arena_stride = e->arena_stride[l];
+    for (int k = 0; k < CSL_NUM_LISTS; k++) a.list_base[k] = e->list_base[l][k];
+    a.layer = (uint32_t)l;
+    a.fanout = (uint32_t)e->cfg.fanout[l];
+    a.W = a.fanout + 1;
+    const dim3 blk(TN);
+    const dim3 grid_in((unsigned)((e->fcap[l] + TN - 1) / TN), S);
+    const dim3 grid_out((unsigned)((e->fcap[l + 1] + TN - 1) / TN), S);
+    {
+      Timed t(e, KN_DEGREE, e->stream);
+      hipLaunchKernelGGL(k_degree, grid_in, blk, 0, e->stream, a);
+    }
+    {
+      Timed t(e, KN_SCAN_A, e->stream);
+      hipLaunchKernelGGL(k_scan<0>, dim3(S), blk, 0, e->stream, a);
+    }
+    {
+      Timed t(e, KN_SAMPLE, e->stream);
+      hipLaunchKernelGGL(k_sample, grid_in, blk, 0, e->stream, a);
+    }
+    {
+      Timed t(e, KN_FLAG, e->stream);
+      hipLaunchKernelGGL(k_flag, grid_in, blk, 0, e->stream, a);
+    }
+    {
+      Timed t(e, KN_SCAN_B, e->stream);
+      hipLaunchKernelGGL(k_scan<1>, dim3(S), blk, 0, e->stream, a);
+    }
+    {
+      Timed t(e, KN_EMIT, e->stream);
+      hipLaunchKernelGGL(k_emit, grid_in, blk, 0, e->stream, a);
+    }
+    {
+      Timed t(e, KN_FINISH, e->stream);
+      hipLaunchKernelGGL(k_finish, grid_out, blk, 0, e->stream, a);
+    }
+  }
+  HIPCHECK(hipGetLastError());
+  for (int s = 0; s < n_batches && s < S; s++) e->pos_ub[s] += e->worst_draws;
+  e->dirty = true;
+  e->meta_valid[slot] = 0;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* csl_last_error(void) { return g_err; }
+int csl_abi_version(void) { return CSL_ABI_VERSION; }
+const char* csl_kernel_name(int32_t k) { return (k >= 0 && k < CSL_NUM_KERNELS) ? kKernelNames[k] : ""; }
+
+void csl_destroy(csl_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->cfg.device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  if (e->rng_stream) hipStreamSynchronize(e->rng_stream);
+  for (auto& te : e->timed) {
+    hipEventDestroy(te.a);
+    hipEventDestroy(te.b);
+  }
+  for (auto ev : e->event_pool) hipEventDestroy(ev);
+  void* ptrs[] = {e->rowinfo, e->indices, e->wl,      e->nodes, e->seedbuf, e->ring,  e->mt_state, e->rngpos,
+                  e->rngbase, e->entry,   e->ninfo,   e->hasedge, e->selfpos, e->cand, e->cflag,   e->tcnt,
+                  e->fsize,   e->meta,    e->desc_dev};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  for (int l = 0; l <= CSL_MAX_LAYERS; l++)
+    if (e->fr[l]) hipFree(e->fr[l]);
+  for (int l = 0; l < CSL_MAX_LAYERS; l++)
+    if (e->arena[l]) hipFree(e->arena[l]);
+  if (e->desc_host) hipHostFree(e->desc_host);
+  if (e->rng_event) hipEventDestroy(e->rng_event);
+  if (e->stream) hipStreamDestroy(e->stream);
+  if (e->rng_stream) hipStreamDestroy(e->rng_stream);
+  delete e;
+}
+
+static int create_impl(const csl_config* cfg, csl_engine* e) {
+  e->cfg = *cfg;
+  const int S = e->S = cfg->n_streams, P = e->P = cfg->n_parts, L = e->L = cfg->n_layers;
+  e->slots = cfg->n_slots;
+  e->N = (uint32_t)cfg->num_nodes;
+  e->E = (size_t)cfg->num_edges;
+  HIPCHECK(hipSetDevice(cfg->device));
+  HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  HIPCHECK(hipStreamCreateWithFlags(&e->rng_stream, hipStreamNonBlocking));
+  HIPCHECK(hipEventCreateWithFlags(&e->rng_event, hipEventDisableTiming));
+  const size_t N = e->N;
+  // ---- graph upload + packing (int64 CSR -> rowinfo / u32 indices)
+  DMALLOC(e->rowinfo, N);
+  DMALLOC(e->indices, e->E);
+  {
+    long long* tmp = nullptr;
+    const size_t chunk = (size_t)64 << 20;  // elements per staging chunk
+    const size_t tmp_n = (N + 1 > chunk ? N + 1 : chunk);
+    hipError_t r = hipMalloc((void**)&tmp, tmp_n * sizeof(long long));
+    if (r != hipSuccess) return fail(CSL_E_NOMEM, "staging hipMalloc failed: %s", hipGetErrorString(r));
+    hipError_t er = hipMemcpy(tmp, cfg->indptr, (N + 1) * sizeof(long long), hipMemcpyHostToDevice);
+    if (er == hipSuccess) {
+      hipLaunchKernelGGL(k_pack_rows, dim3(1024), dim3(256), 0, e->stream, tmp, e->rowinfo, N);
+      er = hipStreamSynchronize(e->stream);
+    }
+    for (size_t o = 0; er == hipSuccess && o < e->E; o += chunk) {
+      const size_t n = e->E - o < chunk ? e->E - o : chunk;
+      er = hipMemcpy(tmp, cfg->indices + o, n * sizeof(long long), hipMemcpyHostToDevice);
+      if (er != hipSuccess) break;
+      hipLaunchKernelGGL(k_pack_indices, dim3(2048), dim3(256), 0, e->stream, tmp, e->indices + o, n);
+      er = hipStreamSynchronize(e->stream);
+    }
+    if (er == hipSuccess && cfg->workload) {
+      DMALLOC(e->wl, N);
+      er = hipMemcpy(tmp, cfg->workload, N * sizeof(int), hipMemcpyHostToDevice);
+      if (er == hipSuccess) {
+        hipLaunchKernelGGL(k_pack_wl, dim3(1024), dim3(256), 0, e->stream, (const int*)tmp, e->wl, N);
+        er = hipStreamSynchronize(e->stream);
+      }
+    }
+    hipFree(tmp);
+    if (er != hipSuccess) return fail(CSL_E_HIP, "graph upload failed: %s", hipGetErrorString(er));
+  }
+  // ---- capacities
+  e->fcap[0] = (size_t)cfg->max_batch;
+  e->worst_draws = 0;
+  for (int l = 0; l < L; l++) {
+    size_t worst = e->fcap[l] * (size_t)(cfg->fanout[l] + 1);
+    if (worst > N) worst = N;
+    size_t cap = cfg->frontier_cap[l + 1] > 0 ? (size_t)cfg->frontier_cap[l + 1] : worst;
+    if (cap > worst) cap = worst;
+    e->fcap[l + 1] = cap;
+    e->worst_draws += (uint64_t)e->fcap[l] * (uint64_t)cfg->fanout[l];
+  }
+  e->fcap_max = 0;
+  e->ccap_max = 0;
+  for (int l = 0; l < L; l++) {
+    if (e->fcap[l] > e->fcap_max) e->fcap_max = e->fcap[l];
+    const size_t c = ((e->fcap[l] + TN - 1) / TN) * TN * (size_t)(cfg->fanout[l] + 1);
+    if (c > e->ccap_max) e->ccap_max = c;
+    if (c >= 0xFFFFFFFFull) return fail(CSL_E_INVALID, "candidate positions exceed 32 bits");
+  }
+  e->tmax = (uint32_t)((e->fcap_max + TN - 1) / TN);
+  e->nk = (uint32_t)NKINDS(P);
+  // ---- per-stream scratch
+  DMALLOC(e->entry, (size_t)S * N);
+  for (int l = 0; l <= L; l++) DMALLOC(e->fr[l], (size_t)S * e->fcap[l]);
+  DMALLOC(e->ninfo, (size_t)S * e->fcap_max);
+  DMALLOC(e->hasedge, (size_t)S * e->fcap_max);
+  DMALLOC(e->selfpos, (size_t)S * e->fcap_max);
+  DMALLOC(e->cand, (size_t)S * e->ccap_max);
+  DMALLOC(e->cflag, (size_t)S * e->ccap_max);
+  DMALLOC(e->tcnt, (size_t)S * e->nk * e->tmax);
+  DMALLOC(e->fsize, (size_t)S * (CSL_MAX_LAYERS + 1));
+  DMALLOC(e->rngpos, (size_t)S);
+  DMALLOC(e->rngbase, (size_t)S);
+  HIPCHECK(hipMemsetAsync(e->rngpos, 0, sizeof(unsigned long long) * S, e->stream));
+  HIPCHECK(hipMemsetAsync(e->fsize, 0, sizeof(uint32_t) * S * (CSL_MAX_LAYERS + 1), e->stream));
+  hipLaunchKernelGGL(k_fill64, dim3(2048), dim3(256), 0, e->stream, e->entry, (size_t)S * N);
+  // ---- result arenas
+  DMALLOC(e->meta, (size_t)e->slots * S);
+  HIPCHECK(hipMemsetAsync(e->meta, 0, sizeof(csl_sample_meta) * e->slots * S, e->stream));
+  for (int l = 0; l < L; l++) {
+    const size_t F = e->fcap[l], f = (size_t)cfg->fanout[l];
+    const size_t edges = F * f;
+    size_t outs = F * (size_t)(P < (int)f ? P : (int)f);
+    if (outs > edges) outs = edges;
+    size_t cap[CSL_NUM_LISTS];
+    cap[CSL_IN_NODES] = edges;
+    cap[CSL_OUT_NODES] = outs;
+    cap[CSL_OWNED_OUT_NODES] = F;
+    cap[CSL_SELF_IDS_IN] = F;
+    cap[CSL_SELF_IDS_OUT] = F;
+    cap[CSL_TO_IDS] = F;
+    cap[CSL_FROM_IDS] = outs;
+    size_t o = 0;
+    for (int k = 0; k < CSL_NUM_LISTS; k++) {
+      e->list_base[l][k] = o;
+      e->list_cap[l][k] = cap[k];
+      o += (cap[k] + 1) & ~(size_t)1;  // keep 16-byte alignment of every list
+    }
+    e->arena_stride[l] = o;
+    DMALLOC(e->arena[l], (size_t)e->slots * S * o);
+  }
+  DMALLOC(e->desc_dev, (size_t)e->slots * S);
+  HIPCHECK(hipHostMalloc((void**)&e->desc_host, sizeof(BatchDesc) * e->slots * S, hipHostMallocDefault));
+  e->meta_host.resize((size_t)e->slots * S);
+  e->meta_valid.assign(e->slots, 0);
+  // ---- rng
+  const uint32_t lg = cfg->rng_ring_log2 ? cfg->rng_ring_log2 : 26;
+  e->ring_words = 1ull << lg;
+  if (e->ring_words < 4 * e->worst_draws + 2 * 624)
+    return fail(CSL_E_INVALID, "rng_ring_log2=%u too small: one round may draw %llu words", lg,
+                (unsigned long long)e->worst_draws);
+  DMALLOC(e->ring, e->ring_words);
+  DMALLOC(e->mt_state, 624);
+  {
+    uint32_t st[624];
+    mt_seed_host(cfg->rng_seed, st);
+    HIPCHECK(hipMemcpy(e->mt_state, st, sizeof(st), hipMemcpyHostToDevice));
+  }
+  e->pos_ub.assign(S, 0);
+  e->pos_lb.assign(S, 0);
+  e->gen_hi = 0;
+  HIPCHECK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+int csl_create(const csl_config* cfg, csl_engine** out) {
+  if (!cfg || !out) return fail(CSL_E_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != CSL_ABI_VERSION) return fail(CSL_E_INVALID, "abi_version mismatch");
+  if (cfg->n_parts < 1 || cfg->n_parts > CSL_MAX_PARTS) return fail(CSL_E_INVALID, "n_parts must be 1..%d", CSL_MAX_PARTS);
+  if (cfg->n_layers < 1 || cfg->n_layers > CSL_MAX_LAYERS) return fail(CSL_E_INVALID, "n_layers must be 1..%d", CSL_MAX_LAYERS);
+  if (cfg->n_streams < 1 || cfg->n_streams > 1024) return fail(CSL_E_INVALID, "n_streams must be 1..1024");
+  if (cfg->n_slots < 1 || cfg->n_slots > 16) return fail(CSL_E_INVALID, "n_slots must be 1..16");
+  if (cfg->max_batch < 1) return fail(CSL_E_INVALID, "max_batch must be >= 1");
+  if (!cfg->indptr || (!cfg->indices && cfg->num_edges > 0)) return fail(CSL_E_INVALID, "graph arrays missing");
+  // the reference keeps ids and row offsets in `int` (slicer.cpp:9,16;
+  // bipartite.h:55): bit-exact behaviour is only defined below 2^31
+  if (cfg->num_nodes < 1 || cfg->num_nodes >= (1ll << 31)) return fail(CSL_E_INVALID, "num_nodes must be in [1, 2^31)");
+  if (cfg->num_edges < 0 || cfg->num_edges >= (1ll << 31)) return fail(CSL_E_INVALID, "num_edges must be in [0, 2^31)");
+  for (int l = 0; l < cfg->n_layers; l++)
+    if (cfg->fanout[l] < 1 || cfg->fanout[l] > 255) return fail(CSL_E_INVALID, "fanout[%d] must be 1..255", l);
+  if (cfg->indptr[0] != 0 || cfg->indptr[cfg->num_nodes] != cfg->num_edges)
+    return fail(CSL_E_INVALID, "indptr[0] must be 0 and indptr[N] must equal num_edges");
+  for (int64_t v = 0; v < cfg->num_nodes; v++) {
+    const int64_t d = cfg->indptr[v + 1] - cfg->indptr[v];
+    if (d < 0 || d > (int64_t)DEG_MASK) return fail(CSL_E_INVALID, "row %lld: degree %lld unsupported", (long long)v, (long long)d);
+  }
+  for (int64_t k = 0; k < cfg->num_edges; k++)
+    if (cfg->indices[k] < 0 || cfg->indices[k] >= cfg->num_nodes)
+      return fail(CSL_E_INVALID, "indices[%lld]=%lld outside [0,num_nodes)", (long long)k, (long long)cfg->indices[k]);
+  if (cfg->workload)
+    for (int64_t v = 0; v < cfg->num_nodes; v++)
+      if (cfg->workload[v] < 0 || cfg->workload[v] >= cfg->n_parts)
+        return fail(CSL_E_INVALID, "workload[%lld]=%d outside [0,%d)", (long long)v, cfg->workload[v], cfg->n_parts);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(CSL_E_HIP, "no HIP device available (this engine has no CPU path)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(CSL_E_INVALID, "device %d out of range", cfg->device);
+  csl_engine* e = new csl_engine();
+  int r = create_impl(cfg, e);
+  if (r) {
+    char keep[sizeof(g_err)];
+    memcpy(keep, g_err, sizeof(keep));
+    csl_destroy(e);
+    memcpy(g_err, keep, sizeof(keep));
+    return r;
+  }
+  *out = e;
+  return 0;
+}
+
+int csl_set_nodes(csl_engine* e, const int64_t* host_nodes, int64_t n) {
+  if (!e || !host_nodes || n < 0) return fail(CSL_E_INVALID, "bad argument");
+  HIPCHECK(hipSetDevice(e->cfg.device));
+  HIPCHECK(hipStreamSynchronize(e->stream));
+  if (e->nodes) {
+    hipFree(e->nodes);
+    e->dev_bytes -= (int64_t)(e->n_nodes * sizeof(long long));
+    e->nodes = nullptr;
+  }
+  DMALLOC(e->nodes, (size_t)n);
+  HIPCHECK(hipMemcpy(e->nodes, host_nodes, sizeof(long long) * (size_t)n, hipMemcpyHostToDevice));
+  e->n_nodes = n;
+  return 0;
+}
+
+int csl_submit_round(csl_engine* e, int64_t first_batch, int32_t batch_size, int32_t n_batches, int32_t slot) {
+  if (!e) return fail(CSL_E_INVALID, "null engine");
+  if (!e->nodes) return fail(CSL_E_STATE, "csl_set_nodes has not been called");
+  if (slot < 0 || slot >= e->slots) return fail(CSL_E_INVALID, "slot out of range");
+  if (n_batches < 0 || n_batches > e->S) return fail(CSL_E_INVALID, "n_batches must be 0..n_streams");
+  if (batch_size < 1 || batch_size > e->cfg.max_batch) return fail(CSL_E_INVALID, "batch_size must be 1..max_batch");
+  if (first_batch < 0) return fail(CSL_E_INVALID, "first_batch < 0");
+  HIPCHECK(hipSetDevice(e->cfg.device));
+  BatchDesc* d = e->desc_host + (size_t)slot * e->S;
+  for (int s = 0; s < e->S; s++) {
+    long long off = (first_batch + s) * (long long)batch_size;
+    long long cnt = 0;
+    if (s < n_batches && off < e->n_nodes) cnt = e->n_nodes - off < batch_size ? e->n_nodes - off : batch_size;
+    d[s].offset = cnt ? off : 0;
+    d[s].count = (int)cnt;
+    d[s].pad = 0;
+  }
+  return run_round(e, e->nodes, n_batches, slot);
+}
+
+int csl_submit_seeds(csl_engine* e, const int64_t* seeds, const int64_t* offsets, int32_t n_batches, int32_t slot) {
+  if (!e || !offsets) return fail(CSL_E_INVALID, "null argument");
+  if (slot < 0 || slot >= e->slots) return fail(CSL_E_INVALID, "slot out of range");
+  if (n_batches < 0 || n_batches > e->S) return fail(CSL_E_INVALID, "n_batches must be 0..n_streams");
+  HIPCHECK(hipSetDevice(e->cfg.device));
+  const int64_t total = offsets[n_batches] - offsets[0];
+  if (total < 0) return fail(CSL_E_INVALID, "offsets not ascending");
+  BatchDesc* d = e->desc_host + (size_t)slot * e->S;
+  for (int s = 0; s < e->S; s++) {
+    d[s].offset = 0;
+    d[s].count = 0;
+    d[s].pad = 0;
+    if (s < n_batches) {
+      const int64_t c = offsets[s + 1] - offsets[s];
+      if (c < 0 || c > e->cfg.max_batch) return fail(CSL_E_INVALID, "minibatch %d has %lld seeds (max_batch %d)", s, (long long)c, e->cfg.max_batch);
+      d[s].offset = offsets[s] - offsets[0];
+      d[s].count = (int)c;
+    }
+  }
+  // the staging buffer is reused: wait for rounds that may still read it
+  HIPCHECK(hipStreamSynchronize(e->stream));
+  if ((size_t)total > e->seedbuf_cap) {
+    if (e->seedbuf) {
+      hipFree(e->seedbuf);
+      e->dev_bytes -= (int64_t)(e->seedbuf_cap * sizeof(long long));
+      e->seedbuf = nullptr;
+    }
+    size_t cap = (size_t)e->S * (size_t)e->cfg.max_batch;
+    DMALLOC(e->seedbuf, cap);
+    e->seedbuf_cap = cap;
+  }
+  if (total) HIPCHECK(hipMemcpy(e->seedbuf, seeds + offsets[0], sizeof(long long) * (size_t)total, hipMemcpyHostToDevice));
+  return run_round(e, e->seedbuf, n_batches, slot);
+}
+
+int csl_sync(csl_engine* e) {
+  if (!e) return fail(CSL_E_INVALID, "null engine");
+  HIPCHECK(hipSetDevice(e->cfg.device));
+  HIPCHECK(hipStreamSynchronize(e->stream));
+  HIPCHECK(hipStreamSynchronize(e->rng_stream));
+  e->dirty = false;
+  int r = collect_timing(e);
+  if (r) return r;
+  return refresh_positions(e);
+}
+
+static int load_meta(csl_engine* e, int32_t slot) {
+  if (e->dirty) {
+    int r = csl_sync(e);
+    if (r) return r;
+  }
+  if (!e->meta_valid[slot]) {
+    HIPCHECK(hipMemcpy(e->meta_host.data() + (size_t)slot * e->S, e->meta + (size_t)slot * e->S,
+                       sizeof(csl_sample_meta) * e->S, hipMemcpyDeviceToHost));
+    e->meta_valid[slot] = 1;
+  }
+  return 0;
+}
+
+int csl_get_meta(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* out) {
+  if (!e || !out) return fail(CSL_E_INVALID, "null argument");
+  if (slot < 0 || slot >= e->slots || stream < 0 || stream >= e->S) return fail(CSL_E_INVALID, "slot/stream out of range");
+  HIPCHECK(hipSetDevice(e->cfg.device));
+  int r = load_meta(e, slot);
+  if (r) return r;
+  *out = e->meta_host[(size_t)slot * e->S + stream];
+  if (out->error) return fail(CSL_E_DEVICE, "device flagged error bits 0x%x in slot %d stream %d", out->error, slot, stream);
+  return 0;
+}
+
+int64_t csl_copy_list(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind, int32_t part,
+                      int64_t* dst, int64_t cap) {
+  if (!e) return fail(CSL_E_INVALID, "null engine");
+  if (slot < 0 || slot >= e->slots || stream < 0 || stream >= e->S || layer < 0 || layer >= e->L || kind < 0 ||
+      kind >= CSL_NUM_LISTS || part < 0 || part >= e->P)
+    return fail(CSL_E_INVALID, "index out of range");
+  hipSetDevice(e->cfg.device);
+  int r = load_meta(e, slot);
+  if (r) return r;
+  const csl_sample_meta& sm = e->meta_host[(size_t)slot * e->S + stream];
+  if (sm.error) return fail(CSL_E_DEVICE, "device flagged error bits 0x%x", sm.error);
+  const csl_layer_meta& m = sm.layer[layer];
+  const int64_t lo = m.off[kind][part], hi = m.off[kind][part + 1];
+  const int64_t n = hi - lo;
+  if (n > cap) return fail(CSL_E_INVALID, "destination too small: need %lld", (long long)n);
+  if (n > 0) {
+    const long long* src = e->arena[layer] + ((size_t)slot * e->S + stream) * e->arena_stride[layer] +
+                           e->list_base[layer][kind] + lo;
+    hipError_t er = hipMemcpy(dst, src, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost);
+    if (er != hipSuccess) return fail(CSL_E_HIP, "hipMemcpy failed: %s", hipGetErrorString(er));
+  }
+  return n;
+}
+
+int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind, const int64_t** out) {
+  if (!e || !out) return fail(CSL_E_INVALID, "null argument");
+  if (slot < 0 || slot >= e->slots || stream < 0 || stream >= e->S || layer < 0 || layer >= e->L || kind < 0 ||
+      kind >= CSL_NUM_LISTS)
+    return fail(CSL_E_INVALID, "index out of range");
+  *out = (const int64_t*)(e->arena[layer] + ((size_t)slot * e->S + stream) * e->arena_stride[layer] +
+                          e->list_base[layer][kind]);
+  return 0;
+}
+
+int csl_frontier_device_ptr(csl_engine* e, int32_t stream, int32_t layer, const uint32_t** out) {
+  if (!e || !out) return fail(CSL_E_INVALID, "null argument");
+  if (stream < 0 || stream >= e->S || layer < 0 || layer > e->L) return fail(CSL_E_INVALID, "index out of range");
+  *out = e->fr[layer] + (size_t)stream * e->fcap[layer];
+  return 0;
+}
+
+int64_t csl_copy_frontier(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int64_t* dst, int64_t cap) {
+  if (!e) return fail(CSL_E_INVALID, "null engine");
+  if (slot < 0 || slot >= e->slots || stream < 0 || stream >= e->S || layer < 0 || layer > e->L)
+    return fail(CSL_E_INVALID, "index out of range");
+  hipSetDevice(e->cfg.device);
+  int r = load_meta(e, slot);
+  if (r) return r;
+  const csl_sample_meta& sm = e->meta_host[(size_t)slot * e->S + stream];
+  const int64_t n = layer < e->L ? sm.layer[layer].frontier : sm.layer[e->L - 1].next_frontier;
+  if (n > cap) return fail(CSL_E_INVALID, "destination too small: need %lld", (long long)n);
+  std::vector<uint32_t> tmp((size_t)n);
+  if (n) {
+    hipError_t er = hipMemcpy(tmp.data(), e->fr[layer] + (size_t)stream * e->fcap[layer], sizeof(uint32_t) * (size_t)n,
+                              hipMemcpyDeviceToHost);
+    if (er != hipSuccess) return fail(CSL_E_HIP, "hipMemcpy failed: %s", hipGetErrorString(er));
+  }
+  for (int64_t i = 0; i < n; i++) dst[i] = (int64_t)tmp[(size_t)i];
+  return n;
+}
+
+int csl_hip_stream(csl_engine* e, void** out) {
+  if (!e || !out) return fail(CSL_E_INVALID, "null argument");
+  *out = (void*)e->stream;
+  return 0;
+}
+
+int csl_timing_enable(csl_engine* e, int32_t on) {
+  if (!e) return fail(CSL_E_INVALID, "null engine");
+  int r = csl_sync(e);
+  if (r) return r;
+  e->timing = on != 0;
+  for (int k = 0; k < CSL_NUM_KERNELS; k++) {
+    e->t_ms[k] = 0;
+    e->t_n[k] = 0;
+  }
+  return 0;
+}
+
+int csl_timing_read(csl_engine* e, double* ms_total, int64_t* launches) {
+  if (!e || !ms_total || !launches) return fail(CSL_E_INVALID, "null argument");
+  int r = csl_sync(e);
+  if (r) return r;
+  for (int k = 0; k < CSL_NUM_KERNELS; k++) {
+    ms_total[k] = e->t_ms[k];
+    launches[k] = e->t_n[k];
+  }
+  return 0;
+}
+
+int csl_rng_peek(csl_engine* e, uint64_t pos, uint32_t* dst, int64_t n) {
+  if (!e || !dst || n < 0) return fail(CSL_E_INVALID, "bad argument");
+  HIPCHECK(hipSetDevice(e->cfg.device));
+  int r = csl_sync(e);
+  if (r) return r;
+  // generate on demand (test hook): extend the window to cover [pos, pos+n)
+  if ((uint64_t)n > e->ring_words / 2) return fail(CSL_E_INVALID, "peek larger than half the ring");
+  while (e->gen_hi < pos + (uint64_t)n) {
+    uint64_t words = pos + (uint64_t)n - e->gen_hi;
+    uint32_t nblocks = (uint32_t)((words + 623) / 624);
+    hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(TN), 0, e->rng_stream, e->mt_state, e->ring,
+                       (unsigned long long)(e->ring_words - 1), (unsigned long long)e->gen_hi, nblocks);
+    e->gen_hi += (uint64_t)nblocks * 624ull;
+    HIPCHECK(hipStreamSynchronize(e->rng_stream));
+  }
+  if (pos + e->ring_words < e->gen_hi) return fail(CSL_E_INVALID, "position already overwritten in the ring");
+  const uint64_t start = pos & (e->ring_words - 1);
+  const uint64_t first = (uint64_t)n < e->ring_words - start ? (uint64_t)n : e->ring_words - start;
+  if (first) HIPCHECK(hipMemcpy(dst, e->ring + start, sizeof(uint32_t) * first, hipMemcpyDeviceToHost));
+  if ((uint64_t)n > first)
+    HIPCHECK(hipMemcpy(dst + first, e->ring, sizeof(uint32_t) * ((uint64_t)n - first), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int64_t csl_device_bytes(csl_engine* e) { return e ? e->dev_bytes : 0; }
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every entry point include/cslicer_hip.h declares, struct layouts agree, and
+argument validation fails loudly without a GPU (no compute is attempted)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cslicer import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "cslicer_hip.h")
+
+
+def header_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(csl_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _abi.load()
+    names = header_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(L, n), "libcslicer_hip.so does not export %s" % n
+    assert sorted(_abi.SYMBOLS) == names
+
+
+def test_abi_version_and_struct_layout():
+    L = _abi.load()
+    assert L.csl_abi_version() == _abi.ABI_VERSION
+    # csl_layer_meta: 4 u32 + 7*(8+1) u32
+    assert C.sizeof(_abi.LayerMeta) == 4 * (4 + 7 * 9)
+    assert C.sizeof(_abi.SampleMeta) == 8 + 16 + 4 * C.sizeof(_abi.LayerMeta)
+    assert L.csl_kernel_name(3).decode() == "k_sample"
+
+
+def test_header_cites_reference_interfaces():
+    src = open(HEADER).read()
+    for cite in ("pyfrontend.cpp:41-70", "slicer.cpp:69-81", "pybipartite.cpp:49-66",
+                 "WorkerPool.cpp:41-50", "bipartite.h:9-26"):
+        assert cite in src
+
+
+def test_create_rejects_bad_config_loudly():
+    indptr = np.array([0, 1, 2], dtype=np.int64)
+    indices = np.array([1, 0], dtype=np.int64)
+    with pytest.raises(_abi.CslError):
+        _abi.Engine(indptr, indices, n_parts=9)
+    with pytest.raises(_abi.CslError):
+        _abi.Engine(indptr, indices, fanouts=(0, 10))
+    with pytest.raises(_abi.CslError):
+        _abi.Engine(np.array([0, 1, 3], dtype=np.int64), indices)  # indptr[N] != E
+    with pytest.raises(_abi.CslError):
+        _abi.Engine(indptr, indices, workload=np.array([0, 7], dtype=np.int32), n_parts=4)
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    indptr = np.array([0, 1, 2], dtype=np.int64)
+    indices = np.array([1, 0], dtype=np.int64)
+    with pytest.raises(_abi.CslError) as ei:
+        _abi.Engine(indptr, indices)
+    assert "no CPU path" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "occ-gnn_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".c")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt, os.path.join(dp, f)

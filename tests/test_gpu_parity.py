@@ -1,0 +1,139 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against
+(a) the golden vectors produced by the unmodified reference and
+(b) the pinned CPU oracle on seeded random inputs in configurations the
+    reference hard-codes away (fanout 15/10/5, 10/10; 1/2/3/8 parts; workload
+    table; several streams).
+Bit-exact: node ids, local indices, -1 sentinels, list order, frontier order,
+rng draw counts."""
+import numpy as np
+import pytest
+
+from golden_util import UNIQUE_SEED_CASES, assert_same_sample, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from cslicer import _abi
+    _abi.load()
+    return _abi
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def test_device_mt19937_matches_std(abi, orc):
+    indptr = np.array([0, 1, 2], dtype=np.int64)
+    indices = np.array([1, 0], dtype=np.int64)
+    e = abi.Engine(indptr, indices, max_batch=2, rng_ring_log2=16)
+    want = orc.mt19937_stream(200_000)
+    assert int(want[9999]) == 4123659995
+    for pos, n in [(0, 1000), (600, 100), (9990, 20), (65000, 2000), (150_000, 30_000)]:
+        got = e.rng_peek(pos, n)
+        np.testing.assert_array_equal(got, want[pos:pos + n], err_msg="pos %d" % pos)
+    e.close()
+
+
+@pytest.mark.parametrize("case", UNIQUE_SEED_CASES)
+def test_golden_parity_single_stream(abi, case):
+    indptr, indices, batches = load_case(case)
+    mb = max(len(b["seeds"]) for b in batches)
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 10, 10), max_batch=mb, n_streams=1)
+    for b, want in enumerate(batches):  # consecutive batches: rng position carries over
+        e.submit_seeds([want["seeds"]])
+        got = e.sample_dict(0)
+        assert_same_sample(got, want, what="%s batch %d" % (case, b))
+        assert got["sampled_edges"] == sum(int(c.sum()) - len(c) for c in want["nbr_counts"])
+    e.close()
+
+
+def test_duplicate_and_bad_seeds_fail_loudly(abi):
+    indptr, indices, batches = load_case("duplicate_seeds")
+    e = abi.Engine(indptr, indices, max_batch=16)
+    e.submit_seeds([batches[0]["seeds"]])
+    with pytest.raises(abi.CslError) as ei:
+        e.meta(0)
+    assert "0x2" in str(ei.value)
+    e.close()
+    e = abi.Engine(indptr, indices, max_batch=16)
+    e.submit_seeds([[1, 2, 10_000]])
+    with pytest.raises(abi.CslError):
+        e.meta(0)
+    e.close()
+
+
+def _rand_graph(n, mean_deg, seed):
+    from cslicer import l0
+    return l0.synth_graph(n, mean_deg, seed=seed)
+
+
+CONFIGS = [
+    # (nodes, mean_deg, n_parts, fanouts, batch, streams, rounds, workload_table)
+    (3000, 20.0, 4, (15, 10, 5), 64, 1, 2, False),
+    (3000, 20.0, 4, (10, 10), 128, 3, 2, False),
+    (5000, 6.0, 1, (15, 10, 5), 100, 2, 2, False),
+    (5000, 30.0, 2, (5, 5, 5, 5), 32, 2, 1, False),
+    (4000, 25.0, 8, (15, 10, 5), 256, 4, 2, False),
+    (4000, 25.0, 3, (10, 10, 10), 200, 2, 2, True),
+    (20000, 50.0, 4, (15, 10, 5), 1024, 2, 1, False),
+    (700, 40.0, 4, (15, 10, 5), 300, 1, 2, False),   # frontier saturates the graph
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[str(c[:5]) for c in CONFIGS])
+def test_oracle_parity_generalised(abi, orc, cfg):
+    n, deg, P, fan, B, S, rounds, table = cfg
+    indptr, indices = _rand_graph(n, deg, seed=n + P)
+    rng = np.random.default_rng(7)
+    wl = rng.integers(0, P, size=n).astype(np.int32) if table else None
+    perm = rng.permutation(n)
+    e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, workload=wl)
+    e.set_nodes(perm)
+    oracles = [orc.Oracle(indptr, indices, n_parts=P, fanouts=fan, workload=wl) for _ in range(S)]
+    nb_total = (n + B - 1) // B
+    for r in range(rounds):
+        first = r * S
+        nb = min(S, nb_total - first)
+        e.submit_round(first, B, nb)
+        for s in range(nb):
+            seeds = perm[(first + s) * B:(first + s + 1) * B]
+            want = oracles[s].sample(seeds)
+            got = e.sample_dict(s)
+            assert_same_sample(got, want, what="round %d stream %d" % (r, s))
+            assert got["sampled_edges"] == want["sampled_edges"]
+            assert got["draws_total"] == want["draws_total"]
+    e.close()
+
+
+def test_partial_last_round_and_short_batch(abi, orc):
+    indptr, indices = _rand_graph(1000, 12.0, seed=3)
+    perm = np.random.default_rng(1).permutation(1000)[:250]   # 250 nodes, batch 100 -> 100,100,50
+    e = abi.Engine(indptr, indices, max_batch=100, n_streams=4)
+    e.set_nodes(perm)
+    e.submit_round(0, 100, 3)
+    for s, seeds in enumerate([perm[0:100], perm[100:200], perm[200:250]]):
+        want = orc.Oracle(indptr, indices).sample(seeds)
+        assert_same_sample(e.sample_dict(s), want, what="stream %d" % s)
+    m = e.meta(3)
+    assert m.n_seeds == 0 and m.layer[0].frontier == 0 and m.layer[2].next_frontier == 0
+    e.close()
+
+
+def test_result_slots_keep_rounds_apart(abi, orc):
+    indptr, indices = _rand_graph(2000, 15.0, seed=5)
+    perm = np.random.default_rng(2).permutation(2000)
+    e = abi.Engine(indptr, indices, max_batch=64, n_streams=2, n_slots=2)
+    e.set_nodes(perm)
+    e.submit_round(0, 64, 2, slot=0)
+    e.submit_round(2, 64, 2, slot=1)   # queued behind round 0, no sync in between
+    o = [orc.Oracle(indptr, indices), orc.Oracle(indptr, indices)]
+    w0 = [o[s].sample(perm[s * 64:(s + 1) * 64]) for s in range(2)]
+    w1 = [o[s].sample(perm[(2 + s) * 64:(3 + s) * 64]) for s in range(2)]
+    for s in range(2):
+        assert_same_sample(e.sample_dict(s, slot=1), w1[s], what="slot1", check_traversal=False)
+        assert_same_sample(e.sample_dict(s, slot=0), w0[s], what="slot0", check_traversal=False)
+    e.close()
