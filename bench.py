@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""bench.py -- cslicer hot path on MI355X: sampled edges/s and minibatch iters/s.
+
+Workload (BASELINE.json configs[1]): ogbn-products-shaped synthetic graph
+(N=2,449,029, mean degree 50.5, pareto degrees), 3-layer
+GraphSAGE fanout 15/10/5 (layer 0 = hop from the seeds), minibatch 1024,
+4 parts with workload v % 4, S engine streams (= S reference workers, each its
+own mt19937(5489)).  One *step* = one round = S minibatches sliced in the same
+kernel launches.  Inputs (CSR, node permutation, mt19937 window) are resident
+in HBM before the timed region.
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL, used
+only for the barrier and the max-over-ranks).  The path shards by minibatch:
+rank r slices its own minibatches, no data-path collective ("weak" scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "occ-gnn_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--streams", type=int, default=64, help="S: minibatches per round")
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--fanout", type=str, default="15,10,5")
+    ap.add_argument("--parts", type=int, default=4)
+    ap.add_argument("--nodes", type=int, default=2_449_029)
+    ap.add_argument("--mean-deg", type=float, default=50.5)
+    ap.add_argument("--graph-seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def get_graph(args, rank, barrier):
+    """Synthetic L0-shaped graph; rank 0 generates and caches, others load."""
+    from cslicer import l0
+    key = "g_n%d_d%g_s%d" % (args.nodes, args.mean_deg, args.graph_seed)
+    cache = os.path.join(os.environ.get("CSLICER_BENCH_CACHE", "/tmp/cslicer_bench_cache"), key)
+    ok = os.path.join(cache, "ok")
+    if rank == 0 and not os.path.exists(ok):
+        os.makedirs(cache, exist_ok=True)
+        t0 = time.time()
+        indptr, indices = l0.synth_graph(args.nodes, args.mean_deg, seed=args.graph_seed)
+        np.save(os.path.join(cache, "indptr.npy"), indptr)
+        np.save(os.path.join(cache, "indices.npy"), indices)
+        open(ok, "w").write("ok\n")
+        sys.stderr.write("[bench] generated graph N=%d E=%d in %.1fs\n" % (args.nodes, indices.shape[0], time.time() - t0))
+    barrier()
+    indptr = np.load(os.path.join(cache, "indptr.npy"))
+    indices = np.load(os.path.join(cache, "indices.npy"), mmap_mode="r")
+    return indptr, np.ascontiguousarray(indices)
+
+
+def path_bytes_reference_types(meta_layers, P):
+    """SURVEY.md 8(d) algorithmic bytes of one minibatch, reference data types
+    (int64 ids/CSR, int32 workload & masks)."""
+    B = 0
+    for m in meta_layers:
+        F, E, D, U = m["F"], m["E"], m["D"], m["U"]
+        Ug = m["in_total"]
+        O = m["list_total"]
+        B += F * (8 + 16 + 4) + E * (8 + 4) + D * 4 + (E + F) * 4 + U * (4 + 8) + E * 4 + Ug * (4 + 8) + 8 * O
+        B += 4 * (U + Ug + m["out_total"])
+    return B
+
+
+def kernel_bytes_device_layout(name, m, P):
+    """Algorithmic bytes one launch of `name` must move for one minibatch-layer,
+    in the engine's own HBM layout (u32 ids internally, int64 exported lists).
+    Stated per term in DESIGN.md section 5."""
+    F, E, D, U, C = m["F"], m["E"], m["D"], m["U"], m["C"]
+    if name == "k_degree":
+        return F * (4 + 8 + 8 + 4)            # id, rowinfo gather, ninfo store, entry.self store
+    if name == "k_sample":
+        # ids + ninfo, rng words, neighbour gather, candidate store, dedup atomic, part mask
+        return F * (4 + 8) + D * 4 + E * 4 + C * 4 + E * 4 + F * 4
+    if name == "k_flag":
+        return C * 4 + (E + F) * 8 + C * 1 + F * 4   # candidates, entry gathers, flag bytes, ids
+    if name == "k_emit":
+        return C * (1) + (U + m["in_total"]) * 4 + U * 4 + m["in_total"] * (8 + 4) + F * (4 + 4) + m["node_lists"] * 8 + F * 4
+    if name == "k_finish":
+        return U * (4 + 8 + 8) + F * (4 + 8)
+    return 0
+
+
+def main():
+    args = parse()
+    fan = tuple(int(x) for x in args.fanout.split(","))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        sys.stderr.write("[bench] --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n" % (args.gpus, world))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from cslicer import _abi
+    _abi.load()  # raises if the HIP library is missing: no fallback
+    indptr, indices = get_graph(args, rank, barrier)
+    N = indptr.shape[0] - 1
+    S, B, P = args.streams, args.batch, args.parts
+    perm = np.random.default_rng(1).permutation(N).astype(np.int64)
+    eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2,
+                      device=local_rank)
+    eng.set_nodes(perm)
+    n_batches = (N + B - 1) // B
+    rounds_per_epoch = max(1, n_batches // S)  # full rounds only: every step does S minibatches
+
+    def run_round(step):
+        # weak scaling: rank r takes its own rounds; wraps around the epoch
+        ridx = (step * world + rank) % rounds_per_epoch
+        eng.submit_round(ridx * S, B, S, slot=step & 1)
+
+    def timed(nsteps, first_step):
+        barrier()
+        eng.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(nsteps):
+            run_round(first_step + k)
+        eng.sync()
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t0
+
+    for w in range(args.warmup):
+        run_round(w)
+    eng.sync()
+    dt = timed(args.steps, args.warmup)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- units processed: read the last two rounds' metas (both slots)
+    def slot_stats(slot):
+        layers = [dict(F=0, E=0, D=0, U=0, C=0, in_total=0, out_total=0, node_lists=0, list_total=0) for _ in fan]
+        for s in range(S):
+            m = eng.meta(s, slot)
+            for l, f in enumerate(fan):
+                lm = m.layer[l]
+                d = layers[l]
+                d["F"] += lm.frontier
+                d["E"] += lm.sampled_edges
+                d["D"] += lm.draws
+                d["U"] += lm.next_frontier
+                d["C"] += lm.frontier * (f + 1)
+                tot = [int(lm.off[k][P]) for k in range(_abi.NUM_LISTS)]
+                d["in_total"] += tot[_abi.IN_NODES]
+                d["out_total"] += tot[_abi.OUT_NODES]
+                d["node_lists"] += sum(tot) - tot[_abi.IN_NODES]
+                d["list_total"] += sum(tot) + tot[_abi.OUT_NODES]  # + indptr ones
+        return layers
+
+    stats = slot_stats((args.warmup + args.steps - 1) & 1)
+    edges_per_round = sum(d["E"] for d in stats)
+    total_edges = edges_per_round * args.steps
+    if dist is not None:
+        t = torch.tensor([float(total_edges)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_edges = float(t.item())
+    iters = args.steps * S * world
+    value = total_edges / dt
+
+    out = {
+        "metric": "sampled_edges_per_sec",
+        "value": value,
+        "unit": "edges/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "iters_per_sec": iters / dt,
+        "config": {
+            "workload": "products-like synthetic (N=%d, mean degree %g, pareto degrees, seed %d), GraphSAGE fanout %s "
+                        "(layer 0 = seeds' hop), minibatch %d, %d parts (v %% %d), engine-only (sample+slice)"
+                        % (N, args.mean_deg, args.graph_seed, "/".join(map(str, fan)), B, P, P),
+            "streams": S,
+            "minibatches_per_step": S,
+            "exported_lists": "int64",
+            "sampled_edges_per_minibatch": edges_per_round / S,
+        },
+    }
+
+    if rank == 0:
+        # ---- per-kernel HIP-event timing pass (engine's own stream) for the roofline
+        if not args.no_kernel_timing:
+            eng.timing_enable(True)
+            t_ev = time.perf_counter()
+            for k in range(args.steps):
+                run_round(args.warmup + args.steps + k)
+            eng.sync()
+            t_ev = time.perf_counter() - t_ev
+            tim = eng.timing_read()
+            eng.timing_enable(False)
+            stats2 = slot_stats((args.warmup + 2 * args.steps - 1) & 1)
+            per_kernel = {}
+            for name, (ms, n) in tim.items():
+                if n == 0 or name in ("k_seeds", "k_scan_need", "k_scan_lists", "k_mt19937_fill"):
+                    per_kernel[name] = {"ms_total": ms, "launches": n}
+                    continue
+                nbytes = sum(kernel_bytes_device_layout(name, d, P) for d in stats2) * args.steps
+                per_kernel[name] = {"ms_total": ms, "launches": n, "avg_us": 1e3 * ms / n,
+                                    "alg_bytes_per_launch": nbytes / n,
+                                    "achieved_GBs": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None}
+            dom = max((k for k in per_kernel if "achieved_GBs" in per_kernel[k]),
+                      key=lambda k: per_kernel[k]["ms_total"])
+            d = per_kernel[dom]
+            out["roofline"] = {
+                "bound": "hbm", "kernel": dom, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": d["avg_us"], "alg_bytes_per_launch": d["alg_bytes_per_launch"],
+            }
+            out["kernels"] = per_kernel
+            out["timing_pass_ms_per_step"] = 1e3 * t_ev / args.steps
+        # whole path against the HBM roof, SURVEY 8(d) byte formula (reference data types)
+        per_iter = [{k: v / S for k, v in d.items()} for d in stats]
+        pb = path_bytes_reference_types(per_iter, P)
+        out["path_roofline"] = {
+            "alg_bytes_per_minibatch": pb,
+            "achieved_GBs": pb * (args.steps * S) / dt / 1e9 if world == 1 else pb * iters / dt / 1e9 / world,
+            "peak_GBs": HBM_PEAK_GBS,
+        }
+        out["path_roofline"]["frac"] = out["path_roofline"]["achieved_GBs"] / HBM_PEAK_GBS
+
+        # ---- CPU baseline: the oracle (port of the reference algorithm) on host cores
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as orc
+            cores = min(16, os.cpu_count() or 1)
+            probe = [perm[i * B:(i + 1) * B] for i in range(2)]
+            sec1, e1 = orc.bench(indptr, indices, probe, n_parts=P, fanouts=fan, threads=1)
+            per_iter_s = sec1 / 2
+            nb = int(max(cores, min(n_batches, args.cpu_seconds / per_iter_s)))
+            nb = (nb // cores) * cores
+            sample = [perm[i * B:(i + 1) * B] for i in range(nb)]
+            secT, eT = orc.bench(indptr, indices, sample, n_parts=P, fanouts=fan, threads=cores)
+            out["cpu_baseline"] = {
+                "value": eT / secT, "unit": "edges/s", "cores": cores, "kind": "port",
+                "sample": "%d minibatches of the same workload (first %d of the permutation), %d threads, one "
+                          "slicer per thread, incl. per-sample deep copy; %.2fs" % (nb, nb, cores, secT),
+                "iters_per_sec": nb / secT,
+                "single_thread": {"value": e1 / sec1, "iters_per_sec": 2 / sec1, "sample": "2 minibatches"},
+            }
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
