@@ -87,17 +87,23 @@ def kernel_bytes_device_layout(name, m, P):
     in the engine's own HBM layout (u32 ids internally, int64 exported lists).
     Stated per term in DESIGN.md section 5."""
     F, E, D, U, C = m["F"], m["E"], m["D"], m["U"], m["C"]
+    Q = E + F  # bucket queue entries: one per real candidate
     if name == "k_degree":
-        return F * (4 + 8 + 8 + 4)            # id, rowinfo gather, ninfo store, entry.self store
+        return F * (4 + 8 + 8)                 # id, rowinfo gather, ninfo store
     if name == "k_sample":
-        # ids + ninfo, rng words, neighbour gather, candidate store, dedup atomic, part mask
-        return F * (4 + 8) + D * 4 + E * 4 + C * 4 + E * 4 + F * 4
-    if name == "k_flag":
-        return C * 4 + (E + F) * 8 + C * 1 + F * 4   # candidates, entry gathers, flag bytes, ids
+        # ids + ninfo, rng words, neighbour gather, candidate + flag store, part mask
+        return F * (4 + 8) + D * 4 + E * 4 + C * (4 + 1) + F * 4
+    if name == "k_scatter":
+        return C * 4 + Q * 8                   # candidates in, {id, position} pairs out
+    if name == "k_bucket":
+        return Q * 8 + Q * 1 + F * 4           # pairs in (second pass hits L2), flag bytes, first positions
+    if name == "k_count":
+        return C * 1
     if name == "k_emit":
-        return C * (1) + (U + m["in_total"]) * 4 + U * 4 + m["in_total"] * (8 + 4) + F * (4 + 4) + m["node_lists"] * 8 + F * 4
-    if name == "k_finish":
-        return U * (4 + 8 + 8) + F * (4 + 8)
+        return (C * 1 + (U + m["in_total"]) * 4 + U * 4 + m["in_total"] * (8 + 4)
+                + F * (4 + 4) + m["node_lists"] * 8 + F * 4)
+    if name == "k_selfin":
+        return F * (4 + 4 + 4 + 8)
     return 0
 
 
@@ -229,7 +235,7 @@ def main():
             stats2 = slot_stats((args.warmup + 2 * args.steps - 1) & 1)
             per_kernel = {}
             for name, (ms, n) in tim.items():
-                if n == 0 or name in ("k_seeds", "k_scan_need", "k_scan_lists", "k_mt19937_fill"):
+                if n == 0 or name in ("k_seeds", "k_scan_need", "k_scan_lists", "k_scan_buckets", "k_mt19937_fill"):
                     per_kernel[name] = {"ms_total": ms, "launches": n}
                     continue
                 nbytes = sum(kernel_bytes_device_layout(name, d, P) for d in stats2) * args.steps

@@ -50,7 +50,8 @@ enum {
   CSL_ERR_RNG_WINDOW = 1,     /* a draw fell outside the generated mt19937 window */
   CSL_ERR_DUP_SEED = 2,       /* repeated seed id in one minibatch (unsupported) */
   CSL_ERR_SEED_RANGE = 4,     /* seed id outside [0, num_nodes) */
-  CSL_ERR_FRONTIER_CAP = 8    /* a frontier outgrew its configured capacity */
+  CSL_ERR_FRONTIER_CAP = 8,   /* a frontier outgrew its configured capacity */
+  CSL_ERR_BUCKET_FULL = 16    /* an LDS dedup bucket overflowed (hash skew) */
 };
 
 /* list kinds: members of BiPartite (bipartite.h:9-26) */
@@ -163,7 +164,7 @@ int csl_hip_stream(csl_engine* e, void** out);
 
 /* time the dominant kernels of the last rounds with HIP events on the
  * engine's own stream: enable, run rounds, read back per-kernel totals */
-#define CSL_NUM_KERNELS 9
+#define CSL_NUM_KERNELS 12
 int csl_timing_enable(csl_engine* e, int32_t on);
 int csl_timing_read(csl_engine* e, double* ms_total /*[CSL_NUM_KERNELS]*/,
                     int64_t* launches /*[CSL_NUM_KERNELS]*/);

@@ -15,13 +15,13 @@ MAX_PARTS = 8
 MAX_LAYERS = 4
 ABI_VERSION = 1
 NUM_LISTS = 7
-NUM_KERNELS = 9
+NUM_KERNELS = 12
 (IN_NODES, OUT_NODES, OWNED_OUT_NODES, SELF_IDS_IN, SELF_IDS_OUT, TO_IDS, FROM_IDS) = range(7)
 LIST_KINDS = {
     "in_nodes": IN_NODES, "out_nodes": OUT_NODES, "owned_out_nodes": OWNED_OUT_NODES,
     "self_ids_in": SELF_IDS_IN, "self_ids_out": SELF_IDS_OUT, "to_ids": TO_IDS, "from_ids": FROM_IDS,
 }
-ERR_BITS = {1: "RNG_WINDOW", 2: "DUP_SEED", 4: "SEED_RANGE", 8: "FRONTIER_CAP"}
+ERR_BITS = {1: "RNG_WINDOW", 2: "DUP_SEED", 4: "SEED_RANGE", 8: "FRONTIER_CAP", 16: "BUCKET_FULL"}
 
 # every symbol include/cslicer_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

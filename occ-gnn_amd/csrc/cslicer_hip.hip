@@ -9,8 +9,10 @@
 //
 //   candidate position  c = i * (fanout+1) + slot     (i = index in frontier,
 //                                                      slot 0 = the node itself)
-//   first occurrence    = smallest c                   (atomicMin into a dense
-//                                                      per-stream table, the
+//   first occurrence    = smallest c                   (candidates are hash-
+//                                                      partitioned into buckets;
+//                                                      each bucket is resolved in
+//                                                      an LDS hash table, the
 //                                                      DuplicateRemover mask)
 //   stable lists        = exclusive scans of flags in c / i order
 //   rng word of (i,j)   = base + fanout * #{i' < i : deg(i') >= fanout} + j
@@ -20,9 +22,10 @@
 //   indices  u32[E]      CSR neighbours (ids < 2^31)
 //   wl       u8[N]       owner part (absent => v % P)
 //   rng ring u32[2^k]    mt19937 outputs, absolute position & mask
-//   per stream: entry u64[N] = {hi: index in frontier, lo: min edge position /
-//   in-node rank}; frontier / candidate / flag scratch; tile counters; result
-//   arena (int64 lists in BiPartite layout, see include/cslicer_hip.h).
+//   per stream: frontier / candidate / flag scratch, bucket queue of
+//   {node id, position} pairs, tile counters; result arena (int64 lists in
+//   BiPartite layout, see include/cslicer_hip.h).  Nothing per stream scales
+//   with N: the dedup state lives in LDS.
 //
 // No CPU fallback exists in this file: every entry point either runs the HIP
 // kernels or returns an error.
@@ -39,9 +42,14 @@
 namespace {
 
 constexpr uint32_t UNSET = 0xFFFFFFFFu;
-constexpr unsigned long long UNSET64 = 0xFFFFFFFFFFFFFFFFull;
+
 constexpr int TN = 256;  // frontier nodes per tile == threads per block
 constexpr int NW = TN / 64;
+constexpr int TPB = 4;         // frontier tiles per k_sample block
+constexpr int HLOG = 12;       // LDS hash table: 2^HLOG slots x 12 B = 48 KiB per block
+constexpr int HCAP = 1 << HLOG;
+constexpr int QMEAN = 1536;    // target candidates per bucket (load <= 0.375)
+constexpr int SCT = 8192;      // candidates per k_scatter block
 constexpr int DEG_BITS = 24;
 constexpr uint32_t DEG_MASK = (1u << DEG_BITS) - 1;
 
@@ -59,10 +67,11 @@ __host__ __device__ constexpr int K_FROM(int P, int g) { return 3 + 5 * P + g; }
 __host__ __device__ constexpr int NKINDS(int P) { return 3 + 6 * P; }
 constexpr int MAXK = 3 + 6 * CSL_MAX_PARTS;
 
-enum { KN_SEEDS = 0, KN_DEGREE, KN_SCAN_A, KN_SAMPLE, KN_FLAG, KN_SCAN_B, KN_EMIT, KN_FINISH, KN_MT };
-const char* const kKernelNames[CSL_NUM_KERNELS] = {"k_seeds", "k_degree", "k_scan_need", "k_sample",
-                                                   "k_flag",  "k_scan_lists", "k_emit", "k_finish",
-                                                   "k_mt19937_fill"};
+enum { KN_SEEDS = 0, KN_DEGREE, KN_SCAN_A, KN_SAMPLE, KN_SCAN_Q, KN_SCATTER, KN_BUCKET, KN_COUNT, KN_SCAN_B,
+       KN_EMIT, KN_SELFIN, KN_MT };
+const char* const kKernelNames[CSL_NUM_KERNELS] = {"k_seeds",   "k_degree", "k_scan_need", "k_sample",
+                                                   "k_scan_buckets", "k_scatter", "k_bucket", "k_count",
+                                                   "k_scan_lists", "k_emit",  "k_selfin",  "k_mt19937_fill"};
 
 // Everything a layer's kernels need; passed by value.
 struct LArgs {
@@ -77,7 +86,6 @@ struct LArgs {
   unsigned long long* rngpos;   // [S] running position
   unsigned long long* rngbase;  // [S] base of the current layer
   // per-stream scratch (stride = elements per stream)
-  unsigned long long* entry;    // [S][N]
   const uint32_t* fr_in;        // [S][fr_in_stride]
   uint32_t* fr_out;             // [S][fr_out_stride]
   size_t fr_in_stride, fr_out_stride;
@@ -85,10 +93,17 @@ struct LArgs {
   unsigned long long* ninfo;    // [S][fcap]
   uint32_t* hasedge;            // [S][fcap]
   uint32_t* selfpos;            // [S][fcap]
+  uint32_t* firstpos;           // [S][fcap] position of the node's first edge occurrence, or UNSET
   size_t fcap;
   uint32_t* cand;               // [S][ccap]
   uint8_t* cflag;               // [S][ccap]
+  uint32_t* crank;              // [S][ccap] in-node rank of first-edge candidates
+  uint2* queue;                 // [S][ccap] bucketed {node id, position | self marker}
   size_t ccap;
+  uint32_t* nbk;                // [S] buckets in use this layer
+  uint32_t* bcnt;               // [S][nbmax+1] bucket sizes -> offsets
+  uint32_t* bcur;               // [S][nbmax]   scatter cursors
+  uint32_t nbmax;
   uint32_t* tcnt;               // [S][nk][tmax]
   uint32_t tmax, nk;
   uint32_t* fsize;              // [S][CSL_MAX_LAYERS+1] frontier sizes
@@ -100,6 +115,8 @@ struct LArgs {
   uint32_t layer, fanout, W;
 };
 
+constexpr uint32_t SELF_BIT = 0x80000000u;
+
 __device__ __forceinline__ uint32_t owner(const LArgs& a, uint32_t v) {
   return a.wl ? (uint32_t)a.wl[v] : (v % a.P);
 }
@@ -107,8 +124,17 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ unsigned long long lt_mask() {
   return (1ull << lane_id()) - 1ull;
 }
-__device__ __forceinline__ uint32_t* entry_lo(unsigned long long* e) { return reinterpret_cast<uint32_t*>(e); }
-__device__ __forceinline__ uint32_t* entry_hi(unsigned long long* e) { return reinterpret_cast<uint32_t*>(e) + 1; }
+// bucket of a node id: multiplicative hash, uniform over [0, nb)
+__device__ __forceinline__ uint32_t bucket_of(uint32_t v, uint32_t nb) {
+  return __umulhi(v * 0x9E3779B1u, nb);
+}
+// slot inside a bucket's LDS table: independent mix of the same id
+__device__ __forceinline__ uint32_t slot_of(uint32_t v) {
+  uint32_t x = v * 0x85EBCA6Bu;
+  x ^= x >> 15;
+  x *= 0xC2B2AE35u;
+  return x >> (32 - HLOG);
+}
 
 // ---- k_seeds: Slicer::get_sample's copy of the batch into `in` (slicer.cpp:70-74)
 struct BatchDesc {
@@ -143,8 +169,8 @@ __global__ __launch_bounds__(TN) void k_seeds(const long long* __restrict__ node
 }
 
 // ---- k_degree: first half of Slicer::neighbour_sample (slicer.cpp:8-9): row
-// offset and degree of every frontier node; marks the node's frontier index in
-// its dedup entry; counts rng consumers and sampled edges per tile.
+// offset and degree of every frontier node; counts rng consumers and sampled
+// edges per tile.
 __global__ __launch_bounds__(TN) void k_degree(LArgs a) {
   const int s = blockIdx.y;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
@@ -159,13 +185,6 @@ __global__ __launch_bounds__(TN) void k_degree(LArgs a) {
     a.ninfo[s * a.fcap + i] = ri;
     need = deg >= a.fanout;
     ne = deg < a.fanout ? deg : a.fanout;
-    uint32_t* hi = entry_hi(&a.entry[(size_t)s * a.N + v]);
-    if (a.layer == 0) {
-      // seeds are the only frontier that can hold repeated ids
-      if (atomicExch(hi, i) != UNSET) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
-    } else {
-      *hi = i;
-    }
   }
   __shared__ uint32_t s_cnt[2];
   if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
@@ -215,6 +234,16 @@ __global__ __launch_bounds__(TN) void k_scan(LArgs a) {
     }
     if (lane_id() == 0) s_tot[k] = run;
   }
+  if (PHASE == 0) {
+    // bucket geometry of this layer: enough buckets that a bucket's distinct
+    // ids stay well below the LDS table; bucket counters start at zero
+    const unsigned long long C = (unsigned long long)F * a.W;
+    uint32_t nb = (uint32_t)((C + QMEAN - 1) / QMEAN);
+    if (nb < 1) nb = 1;
+    if (nb > a.nbmax) nb = a.nbmax;
+    if (threadIdx.x == 0) a.nbk[s] = F ? nb : 0;
+    for (uint32_t b = threadIdx.x; b <= a.nbmax; b += TN) a.bcnt[(size_t)s * (a.nbmax + 1) + b] = 0;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     csl_layer_meta& m = a.meta[s].layer[a.layer];
@@ -250,16 +279,39 @@ __global__ __launch_bounds__(TN) void k_scan(LArgs a) {
   }
 }
 
+// ---- k_scan_buckets: bucket sizes -> queue offsets and scatter cursors
+__global__ __launch_bounds__(TN) void k_scan_buckets(LArgs a) {
+  const int s = blockIdx.x;
+  const uint32_t nb = a.nbk[s];
+  if (threadIdx.x >= 64) return;  // one wave
+  uint32_t* cnt = a.bcnt + (size_t)s * (a.nbmax + 1);
+  uint32_t* cur = a.bcur + (size_t)s * a.nbmax;
+  uint32_t run = 0;
+  for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+    const uint32_t b = b0 + lane_id();
+    const uint32_t x = b < nb ? cnt[b] : 0;
+    uint32_t tot;
+    const uint32_t ex = wave_excl_scan(x, tot);
+    if (b < nb) {
+      cnt[b] = run + ex;
+      cur[b] = run + ex;
+    }
+    run += tot;
+  }
+  if (lane_id() == 0) cnt[nb] = run;
+}
+
 // ---- k_sample: second half of neighbour_sample (slicer.cpp:10-21) + the
 // bookkeeping side of the slice_layer inner loop (slicer.cpp:31-44): writes the
-// candidate stream, atomicMin's each edge candidate's position into the dedup
-// entry of its source node, ORs the owner part of each sampled neighbour into
-// the node's part mask, and counts the per-node list memberships.
+// candidate stream, ORs the owner part of each sampled neighbour into the
+// node's part mask, counts the per-node list memberships and the size of each
+// dedup bucket.  A block walks TPB consecutive tiles so its bucket histogram
+// (LDS) is flushed once per 1024 nodes.
 __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_bh[];  // [nb] bucket histogram
   const int s = blockIdx.y;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
-  const uint32_t tile = blockIdx.x;
-  if (tile * TN >= F) return;
+  if (blockIdx.x * TPB * TN >= F) return;
   __shared__ uint32_t s_v[TN];
   __shared__ unsigned long long s_ri[TN];
   __shared__ uint32_t s_rng[TN];
@@ -267,147 +319,273 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
   __shared__ uint32_t s_wn[NW];
   __shared__ uint32_t s_cnt[5 * CSL_MAX_PARTS];
   const uint32_t n = threadIdx.x;
-  const uint32_t i = tile * TN + n;
   const uint32_t f = a.fanout, W = a.W;
   const uint32_t P = a.P;
-  // phase 1: stage the tile's nodes, rank the rng consumers
-  uint32_t v = 0, need = 0;
-  unsigned long long ri = 0;
-  if (i < F) {
-    v = a.fr_in[s * a.fr_in_stride + i];
-    ri = a.ninfo[s * a.fcap + i];
-    need = (uint32_t)(ri & DEG_MASK) >= f;
-  }
-  const unsigned long long bm = __ballot(need);
-  if (lane_id() == 0) s_wn[n >> 6] = __popcll(bm);
-  if (n < 5 * CSL_MAX_PARTS) s_cnt[n] = 0;
-  s_v[n] = v;
-  s_ri[n] = ri;
-  s_hb[n] = 0;
-  __syncthreads();
-  {
-    uint32_t r = __popcll(bm & lt_mask());
-    for (uint32_t w = 0; w < (n >> 6); w++) r += s_wn[w];
-    const uint32_t tb = a.tcnt[((size_t)s * a.nk + K_NEED) * a.tmax + tile];
-    s_rng[n] = need ? (tb + r) * f : UNSET;
-  }
-  __syncthreads();
-  // phase 2: one candidate per thread per iteration, coalesced over c
-  const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
-  const uint32_t ncand = nodes_here * W;
+  const uint32_t nb = a.nbk[s];
+  for (uint32_t b = n; b < nb; b += TN) s_bh[b] = 0;
   const unsigned long long rbase = a.rngbase[s];
-  unsigned long long* ent = a.entry + (size_t)s * a.N;
-  uint32_t* cand = a.cand + (size_t)s * a.ccap + (size_t)tile * TN * W;
-  for (uint32_t k = n; k < ncand; k += TN) {
-    const uint32_t nn = k / W;
-    const uint32_t slot = k - nn * W;
-    const uint32_t vv = s_v[nn];
-    uint32_t val;
-    if (slot == 0) {
-      val = vv;
-    } else {
-      const unsigned long long r2 = s_ri[nn];
-      const uint32_t deg = (uint32_t)(r2 & DEG_MASK);
-      const unsigned long long off = r2 >> DEG_BITS;
-      const uint32_t j = slot - 1;
-      if (deg < f) {
-        val = j < deg ? a.indices[off + j] : UNSET;
+  for (uint32_t sub = 0; sub < TPB; sub++) {
+    const uint32_t tile = blockIdx.x * TPB + sub;
+    if (tile * TN >= F) break;
+    const uint32_t i = tile * TN + n;
+    // phase 1: stage the tile's nodes, rank the rng consumers
+    uint32_t v = 0, need = 0;
+    unsigned long long ri = 0;
+    if (i < F) {
+      v = a.fr_in[s * a.fr_in_stride + i];
+      ri = a.ninfo[s * a.fcap + i];
+      need = (uint32_t)(ri & DEG_MASK) >= f;
+    }
+    const unsigned long long bm = __ballot(need);
+    __syncthreads();  // previous sub-tile done with the LDS arrays
+    if (lane_id() == 0) s_wn[n >> 6] = __popcll(bm);
+    if (n < 5 * CSL_MAX_PARTS) s_cnt[n] = 0;
+    s_v[n] = v;
+    s_ri[n] = ri;
+    s_hb[n] = 0;
+    __syncthreads();
+    {
+      uint32_t r = __popcll(bm & lt_mask());
+      for (uint32_t w = 0; w < (n >> 6); w++) r += s_wn[w];
+      const uint32_t tb = a.tcnt[((size_t)s * a.nk + K_NEED) * a.tmax + tile];
+      s_rng[n] = need ? (tb + r) * f : UNSET;
+    }
+    __syncthreads();
+    // phase 2: one candidate per thread per iteration, coalesced over c
+    const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
+    const uint32_t ncand = nodes_here * W;
+    const size_t cbase = (size_t)s * a.ccap + (size_t)tile * TN * W;
+    for (uint32_t k = n; k < ncand; k += TN) {
+      const uint32_t nn = k / W;
+      const uint32_t slot = k - nn * W;
+      const uint32_t vv = s_v[nn];
+      uint32_t val;
+      if (slot == 0) {
+        val = vv;
+        atomicAdd(&s_bh[bucket_of(val, nb)], 1u);
       } else {
-        const unsigned long long pos = rbase + s_rng[nn] + j;
-        uint32_t rnd = 0;
-        if (pos >= a.gen_lo && pos < a.gen_hi) {
-          rnd = a.ring[pos & a.ring_mask];
+        const unsigned long long r2 = s_ri[nn];
+        const uint32_t deg = (uint32_t)(r2 & DEG_MASK);
+        const unsigned long long off = r2 >> DEG_BITS;
+        const uint32_t j = slot - 1;
+        if (deg < f) {
+          val = j < deg ? a.indices[off + j] : UNSET;
         } else {
-          atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_RNG_WINDOW);
+          const unsigned long long pos = rbase + s_rng[nn] + j;
+          uint32_t rnd = 0;
+          if (pos >= a.gen_lo && pos < a.gen_hi) {
+            rnd = a.ring[pos & a.ring_mask];
+          } else {
+            atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_RNG_WINDOW);
+          }
+          val = a.indices[off + (rnd % deg)];
         }
-        val = a.indices[off + (rnd % deg)];
+        if (val != UNSET && val != vv) {
+          atomicOr(&s_hb[nn], 1u << owner(a, val));
+          atomicAdd(&s_bh[bucket_of(val, nb)], 1u);
+        }
       }
-      if (val != UNSET && val != vv) {
-        const uint32_t c = (tile * TN) * W + k;
-        atomicMin(entry_lo(&ent[val]), c);
-        atomicOr(&s_hb[nn], 1u << owner(a, val));
+      a.cand[cbase + k] = val;
+      a.cflag[cbase + k] = 0;  // k_bucket overwrites the flags of real candidates
+    }
+    __syncthreads();
+    // phase 3: per-node list memberships (bipartite.h:33-66 push conditions)
+    uint32_t hb = 0, to = 0;
+    const bool act = i < F;
+    if (act) {
+      hb = s_hb[n];
+      to = owner(a, v);
+      a.hasedge[s * a.fcap + i] = hb;
+    }
+    for (uint32_t g = 0; g < P; g++) {
+      const bool own = act && to == g;
+      const bool has = act && ((hb >> g) & 1u);
+      const uint32_t c_out = __popcll(__ballot(has));
+      const uint32_t c_owned = __popcll(__ballot(own && has));
+      const uint32_t c_self = __popcll(__ballot(own));
+      const uint32_t c_to = __popcll(__ballot(own && (hb & ~(1u << g)) != 0));
+      const uint32_t c_from = __popcll(__ballot(has && !own));
+      if (lane_id() == 0) {
+        if (c_out) atomicAdd(&s_cnt[0 * CSL_MAX_PARTS + g], c_out);
+        if (c_owned) atomicAdd(&s_cnt[1 * CSL_MAX_PARTS + g], c_owned);
+        if (c_self) atomicAdd(&s_cnt[2 * CSL_MAX_PARTS + g], c_self);
+        if (c_to) atomicAdd(&s_cnt[3 * CSL_MAX_PARTS + g], c_to);
+        if (c_from) atomicAdd(&s_cnt[4 * CSL_MAX_PARTS + g], c_from);
       }
     }
-    cand[k] = val;
-  }
-  __syncthreads();
-  // phase 3: per-node list memberships (bipartite.h:33-66 push conditions)
-  uint32_t hb = 0, to = 0;
-  const bool act = i < F;
-  if (act) {
-    hb = s_hb[n];
-    to = owner(a, v);
-    a.hasedge[s * a.fcap + i] = hb;
-  }
-  for (uint32_t g = 0; g < P; g++) {
-    const bool own = act && to == g;
-    const bool has = act && ((hb >> g) & 1u);
-    const uint32_t c_out = __popcll(__ballot(has));
-    const uint32_t c_owned = __popcll(__ballot(own && has));
-    const uint32_t c_self = __popcll(__ballot(own));
-    const uint32_t c_to = __popcll(__ballot(own && (hb & ~(1u << g)) != 0));
-    const uint32_t c_from = __popcll(__ballot(has && !own));
-    if (lane_id() == 0) {
-      if (c_out) atomicAdd(&s_cnt[0 * CSL_MAX_PARTS + g], c_out);
-      if (c_owned) atomicAdd(&s_cnt[1 * CSL_MAX_PARTS + g], c_owned);
-      if (c_self) atomicAdd(&s_cnt[2 * CSL_MAX_PARTS + g], c_self);
-      if (c_to) atomicAdd(&s_cnt[3 * CSL_MAX_PARTS + g], c_to);
-      if (c_from) atomicAdd(&s_cnt[4 * CSL_MAX_PARTS + g], c_from);
+    __syncthreads();
+    if (n < 5 * P) {
+      const uint32_t kind5 = n / P, g = n - kind5 * P;
+      a.tcnt[((size_t)s * a.nk + (K_OUT(P, 0) + kind5 * P + g)) * a.tmax + tile] = s_cnt[kind5 * CSL_MAX_PARTS + g];
     }
   }
   __syncthreads();
-  if (n < 5 * P) {
-    const uint32_t kind5 = n / P, g = n - kind5 * P;
-    a.tcnt[((size_t)s * a.nk + (K_OUT(P, 0) + kind5 * P + g)) * a.tmax + tile] = s_cnt[kind5 * CSL_MAX_PARTS + g];
+  uint32_t* gcnt = a.bcnt + (size_t)s * (a.nbmax + 1);
+  for (uint32_t b = n; b < nb; b += TN) {
+    const uint32_t c = s_bh[b];
+    if (c) atomicAdd(&gcnt[b], c);
   }
 }
 
-// ---- k_flag: decides, for every candidate, whether it is the first
-// occurrence of its node (a) in the next frontier (out_dr mask, slicer.cpp:45-49)
-// and (b) among the in_nodes of its slice (order_and_remove_duplicates,
-// bipartite.cpp:4).  Runs after every atomicMin of k_sample has landed.
-// flag byte: bit0 new-frontier, bit1 first-in-node, bits2-4 owner part.
-__global__ __launch_bounds__(TN) void k_flag(LArgs a) {
+// ---- k_scatter: partitions the candidate stream into the dedup buckets.
+// Self entries carry the node's frontier index, edge entries their position;
+// sampled self loops (nd2 == nd1, slicer.cpp:33) never reach a bucket.
+__global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // [2*nb]: histogram, base
+  const int s = blockIdx.y;
+  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  const uint32_t W = a.W;
+  const unsigned long long C = (unsigned long long)F * W;
+  const unsigned long long base = (unsigned long long)blockIdx.x * SCT;
+  if (base >= C) return;
+  const uint32_t nb = a.nbk[s];
+  uint32_t* s_hist = s_dyn;
+  uint32_t* s_base = s_dyn + nb;
+  const uint32_t n = threadIdx.x;
+  for (uint32_t b = n; b < nb; b += TN) s_hist[b] = 0;
+  __syncthreads();
+  const uint32_t* cand = a.cand + (size_t)s * a.ccap;
+  const uint32_t cnt = (C - base) < (unsigned long long)SCT ? (uint32_t)(C - base) : (uint32_t)SCT;
+  for (uint32_t k = n; k < cnt; k += TN) {
+    const uint32_t c = (uint32_t)base + k;
+    const uint32_t val = cand[c];
+    if (val == UNSET) continue;
+    const uint32_t i = c / W;
+    const uint32_t slot = c - i * W;
+    if (slot != 0 && val == cand[c - slot]) continue;
+    atomicAdd(&s_hist[bucket_of(val, nb)], 1u);
+  }
+  __syncthreads();
+  uint32_t* cur = a.bcur + (size_t)s * a.nbmax;
+  for (uint32_t b = n; b < nb; b += TN) {
+    const uint32_t h = s_hist[b];
+    s_base[b] = h ? atomicAdd(&cur[b], h) : 0;
+    s_hist[b] = 0;
+  }
+  __syncthreads();
+  uint2* q = a.queue + (size_t)s * a.ccap;
+  for (uint32_t k = n; k < cnt; k += TN) {
+    const uint32_t c = (uint32_t)base + k;
+    const uint32_t val = cand[c];
+    if (val == UNSET) continue;
+    const uint32_t i = c / W;
+    const uint32_t slot = c - i * W;
+    if (slot != 0 && val == cand[c - slot]) continue;
+    const uint32_t b = bucket_of(val, nb);
+    const uint32_t p = s_base[b] + atomicAdd(&s_hist[b], 1u);
+    q[p] = make_uint2(val, slot == 0 ? (SELF_BIT | i) : c);
+  }
+}
+
+// ---- k_bucket: DuplicateRemover in LDS.  One block owns one bucket of one
+// stream: an open-addressing table {node id -> min edge position, frontier
+// index}.  From it every candidate learns whether it is the first occurrence
+// of its node (a) in the next frontier (out_dr mask, slicer.cpp:45-49) and
+// (b) among the in_nodes of its slice (order_and_remove_duplicates,
+// bipartite.cpp:4).  flag byte: bit0 new-frontier, bit1 first-in-node,
+// bits2-4 owner part.
+__device__ __forceinline__ uint32_t ht_find(const uint32_t* h_key, uint32_t val) {
+  uint32_t h = slot_of(val);
+  for (uint32_t probes = 0; probes < (uint32_t)HCAP; probes++) {
+    const uint32_t k = h_key[h];
+    if (k == val) return h;
+    if (k == UNSET) return UNSET;
+    h = (h + 1) & (HCAP - 1);
+  }
+  return UNSET;
+}
+
+__global__ __launch_bounds__(TN) void k_bucket(LArgs a) {
+  const int s = blockIdx.y;
+  const uint32_t b = blockIdx.x;
+  if (b >= a.nbk[s]) return;
+  __shared__ uint32_t h_key[HCAP];
+  __shared__ uint32_t h_epos[HCAP];
+  __shared__ uint32_t h_self[HCAP];
+  const uint32_t n = threadIdx.x;
+  for (uint32_t i = n; i < (uint32_t)HCAP; i += TN) {
+    h_key[i] = UNSET;
+    h_epos[i] = UNSET;
+    h_self[i] = UNSET;
+  }
+  const uint32_t* off = a.bcnt + (size_t)s * (a.nbmax + 1);
+  const uint32_t q0 = off[b], q1 = off[b + 1];
+  const uint2* q = a.queue + (size_t)s * a.ccap + q0;
+  const uint32_t cnt = q1 - q0;
+  const uint32_t W = a.W;
+  __syncthreads();
+  // insert
+  for (uint32_t k = n; k < cnt; k += TN) {
+    const uint2 e = q[k];
+    const uint32_t val = e.x;
+    uint32_t h = slot_of(val);
+    bool ok = false;
+    for (uint32_t probes = 0; probes < (uint32_t)HCAP; probes++) {
+      uint32_t kk = h_key[h];
+      if (kk == UNSET) kk = atomicCAS(&h_key[h], UNSET, val);
+      if (kk == UNSET || kk == val) {
+        ok = true;
+        break;
+      }
+      h = (h + 1) & (HCAP - 1);
+    }
+    if (!ok) {
+      atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_BUCKET_FULL);
+      continue;
+    }
+    if (e.y & SELF_BIT) {
+      // only the seed layer can hold a node twice
+      if (atomicExch(&h_self[h], e.y & ~SELF_BIT) != UNSET) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
+    } else {
+      atomicMin(&h_epos[h], e.y);
+    }
+  }
+  __syncthreads();
+  // evaluate
+  uint8_t* cflag = a.cflag + (size_t)s * a.ccap;
+  for (uint32_t k = n; k < cnt; k += TN) {
+    const uint2 e = q[k];
+    const uint32_t val = e.x;
+    const uint32_t h = ht_find(h_key, val);
+    if (h == UNSET) continue;  // table overflow, already flagged
+    const uint32_t epos = h_epos[h];
+    const uint32_t g = owner(a, val);
+    if (e.y & SELF_BIT) {
+      const uint32_t i = e.y & ~SELF_BIT;
+      const uint32_t c = i * W;
+      const uint32_t newf = epos > c;  // UNSET compares greater than any position
+      cflag[c] = (uint8_t)(newf | (g << 2));
+      a.firstpos[s * a.fcap + i] = epos;
+    } else {
+      const uint32_t c = e.y;
+      const uint32_t self = h_self[h];
+      const uint32_t fe = epos == c;
+      const uint32_t newf = fe && (self == UNSET || (unsigned long long)self * W > c);
+      cflag[c] = (uint8_t)(newf | (fe << 1) | (g << 2));
+    }
+  }
+}
+
+// ---- k_count: per-tile counts of the two candidate-level flags, in
+// traversal order, for the list scans
+__global__ __launch_bounds__(TN) void k_count(LArgs a) {
   const int s = blockIdx.y;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
   const uint32_t tile = blockIdx.x;
   if (tile * TN >= F) return;
-  __shared__ uint32_t s_v[TN];
   __shared__ uint32_t s_cnt[1 + CSL_MAX_PARTS];
   const uint32_t n = threadIdx.x;
   const uint32_t W = a.W, P = a.P;
-  {
-    const uint32_t i = tile * TN + n;
-    s_v[n] = i < F ? a.fr_in[s * a.fr_in_stride + i] : 0;
-    if (n < 1 + CSL_MAX_PARTS) s_cnt[n] = 0;
-  }
+  if (n < 1 + CSL_MAX_PARTS) s_cnt[n] = 0;
   __syncthreads();
   const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
   const uint32_t ncand = nodes_here * W;
   const uint32_t iters = (ncand + TN - 1) / TN;
-  const unsigned long long* ent = a.entry + (size_t)s * a.N;
   const size_t cbase = (size_t)s * a.ccap + (size_t)tile * TN * W;
   for (uint32_t it = 0; it < iters; it++) {
     const uint32_t k = it * TN + n;
-    uint32_t newf = 0, fe = 0, g = 0;
-    if (k < ncand) {
-      const uint32_t nn = k / W;
-      const uint32_t slot = k - nn * W;
-      const uint32_t val = a.cand[cbase + k];
-      if (val != UNSET) {
-        const uint32_t c = (tile * TN) * W + k;
-        const unsigned long long e = ent[val];
-        const uint32_t epos = (uint32_t)e, self = (uint32_t)(e >> 32);
-        g = owner(a, val);
-        if (slot == 0) {
-          newf = epos > c;  // UNSET compares greater than any position
-        } else if (val != s_v[nn]) {
-          fe = epos == c;
-          newf = fe && (self == UNSET || (unsigned long long)self * W > c);
-        }
-      }
-      a.cflag[cbase + k] = (uint8_t)(newf | (fe << 1) | (g << 2));
-    }
+    const uint32_t fl = k < ncand ? a.cflag[cbase + k] : 0;
+    const uint32_t newf = fl & 1u, fe = (fl >> 1) & 1u, g = fl >> 2;
     const uint32_t c0 = __popcll(__ballot(newf));
     if (lane_id() == 0 && c0) atomicAdd(&s_cnt[0], c0);
     for (uint32_t gg = 0; gg < P; gg++) {
@@ -443,7 +621,6 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   const uint32_t ncand = nodes_here * W;
   const uint32_t iters = (ncand + TN - 1) / TN;
   const size_t cbase = (size_t)s * a.ccap + (size_t)tile * TN * W;
-  unsigned long long* ent = a.entry + (size_t)s * a.N;
   const uint32_t nf_cap = m.next_frontier;  // already clamped to capacity
   for (uint32_t it = 0; it < iters; it++) {
     const uint32_t k = it * TN + n;
@@ -477,7 +654,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][1 + g];
       p += TB(K_IN(P, g));  // local index inside slice g's in_nodes
       ar[a.list_base[CSL_IN_NODES] + m.off[CSL_IN_NODES][g] + p] = (long long)val;
-      *entry_lo(&ent[val]) = p;  // DuplicateRemover::replace's lookup value (mask[v]-1)
+      a.crank[cbase + k] = p;  // DuplicateRemover::replace's lookup value (mask[v]-1)
     }
     __syncthreads();
     if (n < 1 + P) {
@@ -552,7 +729,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       q += TB(K_SELF(P, to));
       const uint32_t pos = m.off[CSL_SELF_IDS_OUT][to] + q;
       ar[a.list_base[CSL_SELF_IDS_OUT] + pos] = outrank_to;
-      a.selfpos[s * a.fcap + i] = pos;  // k_finish fills self_ids_in at the same place
+      a.selfpos[s * a.fcap + i] = pos;  // k_selfin fills self_ids_in at the same place
     }
     if (outrank_to >= 0) {
       uint32_t q = r_owned;
@@ -570,23 +747,18 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
 #undef TB
 }
 
-// ---- k_finish: self_ids_in (replace(self_ids_in), bipartite.cpp:6) and
-// DuplicateRemover::clear (util/duplicate.cpp:28-33).  Every touched entry
-// belongs to exactly one node of the next frontier, which owns its reset.
-__global__ __launch_bounds__(TN) void k_finish(LArgs a) {
+// ---- k_selfin: self_ids_in (replace(self_ids_in), bipartite.cpp:6): the
+// in-node rank of each frontier node inside its own slice, -1 if it was never
+// sampled as a neighbour.
+__global__ __launch_bounds__(TN) void k_selfin(LArgs a) {
   const int s = blockIdx.y;
-  const uint32_t Fn = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer + 1];
-  const uint32_t j = blockIdx.x * TN + threadIdx.x;
-  if (j >= Fn) return;
-  const uint32_t v = a.fr_out[s * a.fr_out_stride + j];
-  unsigned long long* ep = &a.entry[(size_t)s * a.N + v];
-  const unsigned long long e = *ep;
-  const uint32_t epos = (uint32_t)e, self = (uint32_t)(e >> 32);
-  if (self != UNSET) {
-    long long* ar = a.arena + (size_t)s * a.arena_stride;
-    ar[a.list_base[CSL_SELF_IDS_IN] + a.selfpos[s * a.fcap + self]] = epos == UNSET ? -1ll : (long long)epos;
-  }
-  *ep = UNSET64;
+  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  const uint32_t i = blockIdx.x * TN + threadIdx.x;
+  if (i >= F) return;
+  const uint32_t fp = a.firstpos[s * a.fcap + i];
+  long long* ar = a.arena + (size_t)s * a.arena_stride;
+  ar[a.list_base[CSL_SELF_IDS_IN] + a.selfpos[s * a.fcap + i]] =
+      fp == UNSET ? -1ll : (long long)a.crank[(size_t)s * a.ccap + fp];
 }
 
 // ---- k_mt19937_fill: the std::mt19937 stream (slicer.h:33), generated on the
@@ -626,13 +798,6 @@ __global__ __launch_bounds__(TN) void k_mt19937_fill(uint32_t* state, uint32_t* 
   }
   __syncthreads();
   for (uint32_t i = t; i < 624; i += TN) state[i] = buf[cur][i];
-}
-
-// fills u64 words with all ones
-__global__ void k_fill64(unsigned long long* p, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) p[i] = UNSET64;
 }
 
 // packs the reference's int64 CSR into rowinfo / u32 indices on the device
@@ -710,13 +875,19 @@ struct csl_engine {
   size_t fcap_max = 0, ccap_max = 0;
   uint32_t tmax = 0, nk = 0;
   // scratch
-  unsigned long long* entry = nullptr;
   uint32_t* fr[CSL_MAX_LAYERS + 1] = {};
   unsigned long long* ninfo = nullptr;
   uint32_t* hasedge = nullptr;
   uint32_t* selfpos = nullptr;
+  uint32_t* firstpos = nullptr;
   uint32_t* cand = nullptr;
   uint8_t* cflag = nullptr;
+  uint32_t* crank = nullptr;
+  uint2* queue = nullptr;
+  uint32_t* nbk = nullptr;
+  uint32_t* bcnt = nullptr;
+  uint32_t* bcur = nullptr;
+  uint32_t nbmax = 0;
   uint32_t* tcnt = nullptr;
   uint32_t* fsize = nullptr;
   // results
@@ -898,7 +1069,6 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.gen_hi = e->gen_hi;
     a.rngpos = e->rngpos;
     a.rngbase = e->rngbase;
-    a.entry = e->entry;
     a.fr_in = e->fr[l];
     a.fr_out = e->fr[l + 1];
     a.fr_in_stride = e->fcap[l];
@@ -907,10 +1077,17 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.ninfo = e->ninfo;
     a.hasedge = e->hasedge;
     a.selfpos = e->selfpos;
+    a.firstpos = e->firstpos;
     a.fcap = e->fcap_max;
     a.cand = e->cand;
     a.cflag = e->cflag;
+    a.crank = e->crank;
+    a.queue = e->queue;
     a.ccap = e->ccap_max;
+    a.nbk = e->nbk;
+    a.bcnt = e->bcnt;
+    a.bcur = e->bcur;
+    a.nbmax = e->nbmax;
     a.tcnt = e->tcnt;
     a.tmax = e->tmax;
     a.nk = e->nk;
@@ -923,8 +1100,15 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.fanout = (uint32_t)e->cfg.fanout[l];
     a.W = a.fanout + 1;
     const dim3 blk(TN);
-    const dim3 grid_in((unsigned)((e->fcap[l] + TN - 1) / TN), S);
-    const dim3 grid_out((unsigned)((e->fcap[l + 1] + TN - 1) / TN), S);
+    const unsigned tiles_in = (unsigned)((e->fcap[l] + TN - 1) / TN);
+    const size_t ccap_l = (size_t)tiles_in * TN * a.W;
+    const dim3 grid_in(tiles_in, S);
+    const dim3 grid_sample((tiles_in + TPB - 1) / TPB, S);
+    const dim3 grid_scatter((unsigned)((ccap_l + SCT - 1) / SCT), S);
+    unsigned nb_l = (unsigned)((ccap_l + QMEAN - 1) / QMEAN);
+    if (nb_l > e->nbmax) nb_l = e->nbmax;
+    const dim3 grid_bucket(nb_l, S);
+    const size_t lds_hist = (size_t)e->nbmax * sizeof(uint32_t);
     {
       Timed t(e, KN_DEGREE, e->stream);
       hipLaunchKernelGGL(k_degree, grid_in, blk, 0, e->stream, a);
@@ -935,11 +1119,23 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     }
     {
       Timed t(e, KN_SAMPLE, e->stream);
-      hipLaunchKernelGGL(k_sample, grid_in, blk, 0, e->stream, a);
+      hipLaunchKernelGGL(k_sample, grid_sample, blk, lds_hist, e->stream, a);
     }
     {
-      Timed t(e, KN_FLAG, e->stream);
-      hipLaunchKernelGGL(k_flag, grid_in, blk, 0, e->stream, a);
+      Timed t(e, KN_SCAN_Q, e->stream);
+      hipLaunchKernelGGL(k_scan_buckets, dim3(S), blk, 0, e->stream, a);
+    }
+    {
+      Timed t(e, KN_SCATTER, e->stream);
+      hipLaunchKernelGGL(k_scatter, grid_scatter, blk, 2 * lds_hist, e->stream, a);
+    }
+    {
+      Timed t(e, KN_BUCKET, e->stream);
+      hipLaunchKernelGGL(k_bucket, grid_bucket, blk, 0, e->stream, a);
+    }
+    {
+      Timed t(e, KN_COUNT, e->stream);
+      hipLaunchKernelGGL(k_count, grid_in, blk, 0, e->stream, a);
     }
     {
       Timed t(e, KN_SCAN_B, e->stream);
@@ -950,8 +1146,8 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
       hipLaunchKernelGGL(k_emit, grid_in, blk, 0, e->stream, a);
     }
     {
-      Timed t(e, KN_FINISH, e->stream);
-      hipLaunchKernelGGL(k_finish, grid_out, blk, 0, e->stream, a);
+      Timed t(e, KN_SELFIN, e->stream);
+      hipLaunchKernelGGL(k_selfin, grid_in, blk, 0, e->stream, a);
     }
   }
   HIPCHECK(hipGetLastError());
@@ -980,8 +1176,8 @@ void csl_destroy(csl_engine* e) {
   }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   void* ptrs[] = {e->rowinfo, e->indices, e->wl,      e->nodes, e->seedbuf, e->ring,  e->mt_state, e->rngpos,
-                  e->rngbase, e->entry,   e->ninfo,   e->hasedge, e->selfpos, e->cand, e->cflag,   e->tcnt,
-                  e->fsize,   e->meta,    e->desc_dev};
+                  e->rngbase, e->ninfo,   e->hasedge, e->selfpos, e->firstpos, e->cand, e->cflag, e->crank,
+                  e->queue,   e->nbk,     e->bcnt,    e->bcur,    e->tcnt,     e->fsize, e->meta, e->desc_dev};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (int l = 0; l <= CSL_MAX_LAYERS; l++)
@@ -1055,25 +1251,34 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
     if (e->fcap[l] > e->fcap_max) e->fcap_max = e->fcap[l];
     const size_t c = ((e->fcap[l] + TN - 1) / TN) * TN * (size_t)(cfg->fanout[l] + 1);
     if (c > e->ccap_max) e->ccap_max = c;
-    if (c >= 0xFFFFFFFFull) return fail(CSL_E_INVALID, "candidate positions exceed 32 bits");
+    if (c >= 0x80000000ull) return fail(CSL_E_INVALID, "candidate positions exceed 31 bits");
   }
   e->tmax = (uint32_t)((e->fcap_max + TN - 1) / TN);
   e->nk = (uint32_t)NKINDS(P);
   // ---- per-stream scratch
-  DMALLOC(e->entry, (size_t)S * N);
   for (int l = 0; l <= L; l++) DMALLOC(e->fr[l], (size_t)S * e->fcap[l]);
   DMALLOC(e->ninfo, (size_t)S * e->fcap_max);
   DMALLOC(e->hasedge, (size_t)S * e->fcap_max);
   DMALLOC(e->selfpos, (size_t)S * e->fcap_max);
+  DMALLOC(e->firstpos, (size_t)S * e->fcap_max);
   DMALLOC(e->cand, (size_t)S * e->ccap_max);
   DMALLOC(e->cflag, (size_t)S * e->ccap_max);
+  DMALLOC(e->crank, (size_t)S * e->ccap_max);
+  DMALLOC(e->queue, (size_t)S * e->ccap_max);
+  e->nbmax = (uint32_t)((e->ccap_max + QMEAN - 1) / QMEAN);
+  if (e->nbmax < 1) e->nbmax = 1;
+  if (e->nbmax > 8192)
+    return fail(CSL_E_INVALID, "a layer may hold %zu candidates per minibatch; this build supports %d",
+                e->ccap_max, 8192 * QMEAN);
+  DMALLOC(e->nbk, (size_t)S);
+  DMALLOC(e->bcnt, (size_t)S * (e->nbmax + 1));
+  DMALLOC(e->bcur, (size_t)S * e->nbmax);
   DMALLOC(e->tcnt, (size_t)S * e->nk * e->tmax);
   DMALLOC(e->fsize, (size_t)S * (CSL_MAX_LAYERS + 1));
   DMALLOC(e->rngpos, (size_t)S);
   DMALLOC(e->rngbase, (size_t)S);
   HIPCHECK(hipMemsetAsync(e->rngpos, 0, sizeof(unsigned long long) * S, e->stream));
   HIPCHECK(hipMemsetAsync(e->fsize, 0, sizeof(uint32_t) * S * (CSL_MAX_LAYERS + 1), e->stream));
-  hipLaunchKernelGGL(k_fill64, dim3(2048), dim3(256), 0, e->stream, e->entry, (size_t)S * N);
   // ---- result arenas
   DMALLOC(e->meta, (size_t)e->slots * S);
   HIPCHECK(hipMemsetAsync(e->meta, 0, sizeof(csl_sample_meta) * e->slots * S, e->stream));

@@ -36,6 +36,7 @@ def test_abi_version_and_struct_layout():
     assert C.sizeof(_abi.LayerMeta) == 4 * (4 + 7 * 9)
     assert C.sizeof(_abi.SampleMeta) == 8 + 16 + 4 * C.sizeof(_abi.LayerMeta)
     assert L.csl_kernel_name(3).decode() == "k_sample"
+    assert L.csl_kernel_name(_abi.NUM_KERNELS - 1).decode() == "k_mt19937_fill"
 
 
 def test_header_cites_reference_interfaces():

@@ -138,3 +138,26 @@ def test_result_slots_keep_rounds_apart(abi, orc):
         assert_same_sample(e.sample_dict(s, slot=1), w1[s], what="slot1", check_traversal=False)
         assert_same_sample(e.sample_dict(s, slot=0), w0[s], what="slot0", check_traversal=False)
     e.close()
+
+
+def test_hub_graph_many_duplicates_per_bucket(abi, orc):
+    # every node points at a handful of hubs: tens of thousands of candidates
+    # collapse onto a few ids, so single dedup buckets see queues far longer than
+    # their LDS table while holding few distinct ids
+    n = 6000
+    rng = np.random.default_rng(11)
+    hubs = rng.choice(n, size=12, replace=False)
+    rows = [np.sort(rng.choice(hubs, size=11, replace=True)) for _ in range(n)]
+    for h in hubs:
+        rows[h] = np.sort(rng.choice(n, size=400, replace=False))
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in rows], out=indptr[1:])
+    indices = np.concatenate(rows).astype(np.int64)
+    perm = rng.permutation(n)
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 10, 10), max_batch=512, n_streams=2)
+    e.set_nodes(perm)
+    e.submit_round(0, 512, 2)
+    for s in range(2):
+        want = orc.Oracle(indptr, indices).sample(perm[s * 512:(s + 1) * 512])
+        assert_same_sample(e.sample_dict(s), want, what="hub stream %d" % s)
+    e.close()
