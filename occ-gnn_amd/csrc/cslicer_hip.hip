@@ -45,7 +45,7 @@ constexpr uint32_t UNSET = 0xFFFFFFFFu;
 
 constexpr int TN = 256;  // frontier nodes per tile == threads per block
 constexpr int NW = TN / 64;
-constexpr int TPB = 4;         // frontier tiles per k_sample block
+constexpr int TPB = 4;         // frontier tiles per k_sample block on large layers
 constexpr int HLOG = 12;       // LDS hash table: 2^HLOG slots x 12 B = 48 KiB per block
 constexpr int HCAP = 1 << HLOG;
 constexpr int QMEAN = 1536;    // target candidates per bucket (load <= 0.375)
@@ -113,6 +113,9 @@ struct LArgs {
   size_t arena_stride;
   size_t list_base[CSL_NUM_LISTS];  // element offset of each kind inside a stream's arena
   uint32_t layer, fanout, W;
+  unsigned long long wmagic;  // ceil(2^40 / W): exact c / W for c < 2^31, W < 512
+  uint32_t S;
+  uint32_t tpb;               // frontier tiles per k_sample block
 };
 
 constexpr uint32_t SELF_BIT = 0x80000000u;
@@ -121,6 +124,25 @@ __device__ __forceinline__ uint32_t owner(const LArgs& a, uint32_t v) {
   return a.wl ? (uint32_t)a.wl[v] : (v % a.P);
 }
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint32_t div_w(const LArgs& a, uint32_t c) {
+  return (uint32_t)(((unsigned long long)c * a.wmagic) >> 40);
+}
+// XCD-aware block mapping.  Workgroups are dealt round-robin over the 8 XCDs
+// (block id % 8), each XCD with its own L2.  All blocks of one stream are given
+// the same id % 8, in consecutive order, so a stream's scratch (candidates,
+// flags, bucket queue) is touched through ONE L2: scattered narrow stores merge
+// into whole lines there before they reach HBM.  Speed only, never correctness.
+// grid.x = 8 * ceil(S/8) * per_stream.
+__device__ __forceinline__ bool xcd_block(const LArgs& a, uint32_t& x, uint32_t& s) {
+  const uint32_t groups = (a.S + 7u) >> 3;
+  const uint32_t per_stream = gridDim.x / (8u * groups);
+  const uint32_t id = blockIdx.x;
+  const uint32_t j = id >> 3;
+  const uint32_t sl = j / per_stream;
+  x = j - sl * per_stream;
+  s = sl * 8u + (id & 7u);
+  return s < a.S;
+}
 __device__ __forceinline__ unsigned long long lt_mask() {
   return (1ull << lane_id()) - 1ull;
 }
@@ -172,9 +194,9 @@ __global__ __launch_bounds__(TN) void k_seeds(const long long* __restrict__ node
 // offset and degree of every frontier node; counts rng consumers and sampled
 // edges per tile.
 __global__ __launch_bounds__(TN) void k_degree(LArgs a) {
-  const int s = blockIdx.y;
+  uint32_t tile, s;
+  if (!xcd_block(a, tile, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
-  const uint32_t tile = blockIdx.x;
   if (tile * TN >= F) return;
   const uint32_t i = tile * TN + threadIdx.x;
   uint32_t need = 0, ne = 0;
@@ -309,9 +331,10 @@ __global__ __launch_bounds__(TN) void k_scan_buckets(LArgs a) {
 // (LDS) is flushed once per 1024 nodes.
 __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bh[];  // [nb] bucket histogram
-  const int s = blockIdx.y;
+  uint32_t bx, s;
+  if (!xcd_block(a, bx, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
-  if (blockIdx.x * TPB * TN >= F) return;
+  if (bx * a.tpb * TN >= F) return;
   __shared__ uint32_t s_v[TN];
   __shared__ unsigned long long s_ri[TN];
   __shared__ uint32_t s_rng[TN];
@@ -324,8 +347,8 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
   const uint32_t nb = a.nbk[s];
   for (uint32_t b = n; b < nb; b += TN) s_bh[b] = 0;
   const unsigned long long rbase = a.rngbase[s];
-  for (uint32_t sub = 0; sub < TPB; sub++) {
-    const uint32_t tile = blockIdx.x * TPB + sub;
+  for (uint32_t sub = 0; sub < a.tpb; sub++) {
+    const uint32_t tile = bx * a.tpb + sub;
     if (tile * TN >= F) break;
     const uint32_t i = tile * TN + n;
     // phase 1: stage the tile's nodes, rank the rng consumers
@@ -351,42 +374,92 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
       s_rng[n] = need ? (tb + r) * f : UNSET;
     }
     __syncthreads();
-    // phase 2: one candidate per thread per iteration, coalesced over c
+    // phase 2: candidates, coalesced over c.  Each thread keeps SU candidates in
+    // flight: all their rng words are requested, then all their neighbour ids,
+    // before any is consumed (the loads are dependent pairs of HBM round trips).
     const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
     const uint32_t ncand = nodes_here * W;
     const size_t cbase = (size_t)s * a.ccap + (size_t)tile * TN * W;
-    for (uint32_t k = n; k < ncand; k += TN) {
-      const uint32_t nn = k / W;
-      const uint32_t slot = k - nn * W;
-      const uint32_t vv = s_v[nn];
-      uint32_t val;
-      if (slot == 0) {
-        val = vv;
-        atomicAdd(&s_bh[bucket_of(val, nb)], 1u);
-      } else {
-        const unsigned long long r2 = s_ri[nn];
-        const uint32_t deg = (uint32_t)(r2 & DEG_MASK);
-        const unsigned long long off = r2 >> DEG_BITS;
-        const uint32_t j = slot - 1;
-        if (deg < f) {
-          val = j < deg ? a.indices[off + j] : UNSET;
-        } else {
-          const unsigned long long pos = rbase + s_rng[nn] + j;
-          uint32_t rnd = 0;
-          if (pos >= a.gen_lo && pos < a.gen_hi) {
-            rnd = a.ring[pos & a.ring_mask];
+    constexpr int SU = 4;
+    const uint32_t dq = TN / W, dr = TN - dq * W;  // k += TN  =>  node += dq, slot += dr (+carry)
+    uint32_t nn = n / W, slot = n - nn * W;
+    for (uint32_t k0 = n; k0 < ncand; k0 += TN * SU) {
+      uint32_t nnu[SU], slu[SU], vvu[SU], degu[SU], val[SU], rnd[SU];
+      unsigned long long addr[SU], rpos[SU];
+      bool live[SU], gat[SU], rq[SU];
+#pragma unroll
+      for (int u = 0; u < SU; u++) {
+        live[u] = k0 + u * TN < ncand;
+        nnu[u] = nn;
+        slu[u] = slot;
+        nn += dq;
+        slot += dr;
+        if (slot >= W) {
+          slot -= W;
+          nn++;
+        }
+        val[u] = UNSET;
+        gat[u] = false;
+        rq[u] = false;
+        addr[u] = 0;
+        rpos[u] = 0;
+        vvu[u] = 0;
+        degu[u] = 1;
+        rnd[u] = 0;
+        if (live[u]) {
+          vvu[u] = s_v[nnu[u]];
+          if (slu[u] == 0) {
+            val[u] = vvu[u];
+          } else {
+            const unsigned long long r2 = s_ri[nnu[u]];
+            const uint32_t deg = (uint32_t)(r2 & DEG_MASK);
+            const uint32_t j = slu[u] - 1;
+            degu[u] = deg;
+            addr[u] = r2 >> DEG_BITS;
+            if (deg < f) {
+              gat[u] = j < deg;
+              addr[u] += j;
+            } else {
+              gat[u] = true;
+              rq[u] = true;
+              rpos[u] = rbase + s_rng[nnu[u]] + j;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < SU; u++) {
+        if (rq[u]) {
+          if (rpos[u] >= a.gen_lo && rpos[u] < a.gen_hi) {
+            rnd[u] = a.ring[rpos[u] & a.ring_mask];
           } else {
             atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_RNG_WINDOW);
           }
-          val = a.indices[off + (rnd % deg)];
-        }
-        if (val != UNSET && val != vv) {
-          atomicOr(&s_hb[nn], 1u << owner(a, val));
-          atomicAdd(&s_bh[bucket_of(val, nb)], 1u);
         }
       }
-      a.cand[cbase + k] = val;
-      a.cflag[cbase + k] = 0;  // k_bucket overwrites the flags of real candidates
+#pragma unroll
+      for (int u = 0; u < SU; u++) {
+        if (gat[u]) val[u] = a.indices[addr[u] + (rq[u] ? rnd[u] % degu[u] : 0u)];
+      }
+#pragma unroll
+      for (int u = 0; u < SU; u++) {
+        if (live[u]) {
+          if (slu[u] == 0) {
+            atomicAdd(&s_bh[bucket_of(val[u], nb)], 1u);
+          } else if (val[u] != UNSET) {
+            if (val[u] == vvu[u]) {
+              // a sampled self loop only re-adds the self edge (slicer.cpp:33-35,
+              // bipartite.h:34): it is neither an edge nor new to the frontier
+              val[u] = UNSET;
+            } else {
+              atomicOr(&s_hb[nnu[u]], 1u << owner(a, val[u]));
+              atomicAdd(&s_bh[bucket_of(val[u], nb)], 1u);
+            }
+          }
+          a.cand[cbase + k0 + u * TN] = val[u];
+          a.cflag[cbase + k0 + u * TN] = 0;  // k_bucket overwrites the flags of real candidates
+        }
+      }
     }
     __syncthreads();
     // phase 3: per-node list memberships (bipartite.h:33-66 push conditions)
@@ -429,14 +502,15 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
 
 // ---- k_scatter: partitions the candidate stream into the dedup buckets.
 // Self entries carry the node's frontier index, edge entries their position;
-// sampled self loops (nd2 == nd1, slicer.cpp:33) never reach a bucket.
+// holes (short rows, sampled self loops) never reach a bucket.
 __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // [2*nb]: histogram, base
-  const int s = blockIdx.y;
+  uint32_t bx, s;
+  if (!xcd_block(a, bx, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
   const uint32_t W = a.W;
   const unsigned long long C = (unsigned long long)F * W;
-  const unsigned long long base = (unsigned long long)blockIdx.x * SCT;
+  const unsigned long long base = (unsigned long long)bx * SCT;
   if (base >= C) return;
   const uint32_t nb = a.nbk[s];
   uint32_t* s_hist = s_dyn;
@@ -444,16 +518,16 @@ __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
   const uint32_t n = threadIdx.x;
   for (uint32_t b = n; b < nb; b += TN) s_hist[b] = 0;
   __syncthreads();
-  const uint32_t* cand = a.cand + (size_t)s * a.ccap;
+  const uint32_t* cand = a.cand + (size_t)s * a.ccap + base;
   const uint32_t cnt = (C - base) < (unsigned long long)SCT ? (uint32_t)(C - base) : (uint32_t)SCT;
-  for (uint32_t k = n; k < cnt; k += TN) {
-    const uint32_t c = (uint32_t)base + k;
-    const uint32_t val = cand[c];
-    if (val == UNSET) continue;
-    const uint32_t i = c / W;
-    const uint32_t slot = c - i * W;
-    if (slot != 0 && val == cand[c - slot]) continue;
-    atomicAdd(&s_hist[bucket_of(val, nb)], 1u);
+  constexpr int CU = 8;
+  for (uint32_t k0 = n; k0 < cnt; k0 += TN * CU) {
+    uint32_t v[CU];
+#pragma unroll
+    for (int u = 0; u < CU; u++) v[u] = k0 + u * TN < cnt ? cand[k0 + u * TN] : UNSET;
+#pragma unroll
+    for (int u = 0; u < CU; u++)
+      if (v[u] != UNSET) atomicAdd(&s_hist[bucket_of(v[u], nb)], 1u);
   }
   __syncthreads();
   uint32_t* cur = a.bcur + (size_t)s * a.nbmax;
@@ -464,16 +538,19 @@ __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
   }
   __syncthreads();
   uint2* q = a.queue + (size_t)s * a.ccap;
-  for (uint32_t k = n; k < cnt; k += TN) {
-    const uint32_t c = (uint32_t)base + k;
-    const uint32_t val = cand[c];
-    if (val == UNSET) continue;
-    const uint32_t i = c / W;
-    const uint32_t slot = c - i * W;
-    if (slot != 0 && val == cand[c - slot]) continue;
-    const uint32_t b = bucket_of(val, nb);
-    const uint32_t p = s_base[b] + atomicAdd(&s_hist[b], 1u);
-    q[p] = make_uint2(val, slot == 0 ? (SELF_BIT | i) : c);
+  for (uint32_t k0 = n; k0 < cnt; k0 += TN * CU) {
+    uint32_t v[CU];
+#pragma unroll
+    for (int u = 0; u < CU; u++) v[u] = k0 + u * TN < cnt ? cand[k0 + u * TN] : UNSET;
+#pragma unroll
+    for (int u = 0; u < CU; u++) {
+      if (v[u] == UNSET) continue;
+      const uint32_t c = (uint32_t)base + k0 + u * TN;
+      const uint32_t i = div_w(a, c);
+      const uint32_t b = bucket_of(v[u], nb);
+      const uint32_t p = s_base[b] + atomicAdd(&s_hist[b], 1u);
+      q[p] = make_uint2(v[u], c == i * W ? (SELF_BIT | i) : c);
+    }
   }
 }
 
@@ -495,116 +572,139 @@ __device__ __forceinline__ uint32_t ht_find(const uint32_t* h_key, uint32_t val)
   return UNSET;
 }
 
-__global__ __launch_bounds__(TN) void k_bucket(LArgs a) {
-  const int s = blockIdx.y;
-  const uint32_t b = blockIdx.x;
+constexpr int BT = 512;  // threads per k_bucket block: 3 blocks x 8 waves share a CU's LDS
+constexpr int RC = 4;    // queue entries a thread keeps in registers between the two phases
+
+__device__ __forceinline__ uint32_t ht_insert(uint32_t* h_key, uint32_t val) {
+  uint32_t h = slot_of(val);
+  for (uint32_t probes = 0; probes < (uint32_t)HCAP; probes++) {
+    uint32_t kk = h_key[h];
+    if (kk == UNSET) kk = atomicCAS(&h_key[h], UNSET, val);
+    if (kk == UNSET || kk == val) return h;
+    h = (h + 1) & (HCAP - 1);
+  }
+  return UNSET;
+}
+
+__global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
+  uint32_t b, s;
+  if (!xcd_block(a, b, s)) return;
   if (b >= a.nbk[s]) return;
   __shared__ uint32_t h_key[HCAP];
   __shared__ uint32_t h_epos[HCAP];
   __shared__ uint32_t h_self[HCAP];
   const uint32_t n = threadIdx.x;
-  for (uint32_t i = n; i < (uint32_t)HCAP; i += TN) {
-    h_key[i] = UNSET;
-    h_epos[i] = UNSET;
-    h_self[i] = UNSET;
-  }
   const uint32_t* off = a.bcnt + (size_t)s * (a.nbmax + 1);
   const uint32_t q0 = off[b], q1 = off[b + 1];
   const uint2* q = a.queue + (size_t)s * a.ccap + q0;
   const uint32_t cnt = q1 - q0;
   const uint32_t W = a.W;
-  __syncthreads();
-  // insert
-  for (uint32_t k = n; k < cnt; k += TN) {
-    const uint2 e = q[k];
-    const uint32_t val = e.x;
-    uint32_t h = slot_of(val);
-    bool ok = false;
-    for (uint32_t probes = 0; probes < (uint32_t)HCAP; probes++) {
-      uint32_t kk = h_key[h];
-      if (kk == UNSET) kk = atomicCAS(&h_key[h], UNSET, val);
-      if (kk == UNSET || kk == val) {
-        ok = true;
-        break;
-      }
-      h = (h + 1) & (HCAP - 1);
-    }
-    if (!ok) {
-      atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_BUCKET_FULL);
-      continue;
-    }
-    if (e.y & SELF_BIT) {
-      // only the seed layer can hold a node twice
-      if (atomicExch(&h_self[h], e.y & ~SELF_BIT) != UNSET) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
-    } else {
-      atomicMin(&h_epos[h], e.y);
-    }
+  uint2 e[RC];
+  uint32_t hs[RC];
+#pragma unroll
+  for (int r = 0; r < RC; r++) e[r] = n + r * BT < cnt ? q[n + r * BT] : make_uint2(UNSET, 0u);
+  for (uint32_t i = n; i < (uint32_t)HCAP; i += BT) {
+    h_key[i] = UNSET;
+    h_epos[i] = UNSET;
+    h_self[i] = UNSET;
   }
   __syncthreads();
-  // evaluate
+  auto insert = [&](const uint2 ee) -> uint32_t {
+    const uint32_t h = ht_insert(h_key, ee.x);
+    if (h == UNSET) {
+      atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_BUCKET_FULL);
+    } else if (ee.y & SELF_BIT) {
+      // only the seed layer can hold a node twice
+      if (atomicExch(&h_self[h], ee.y & ~SELF_BIT) != UNSET) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
+    } else {
+      atomicMin(&h_epos[h], ee.y);
+    }
+    return h;
+  };
+#pragma unroll
+  for (int r = 0; r < RC; r++) hs[r] = e[r].x != UNSET ? insert(e[r]) : UNSET;
+  for (uint32_t k = n + RC * BT; k < cnt; k += BT) insert(q[k]);
+  __syncthreads();
   uint8_t* cflag = a.cflag + (size_t)s * a.ccap;
-  for (uint32_t k = n; k < cnt; k += TN) {
-    const uint2 e = q[k];
-    const uint32_t val = e.x;
-    const uint32_t h = ht_find(h_key, val);
-    if (h == UNSET) continue;  // table overflow, already flagged
+  auto evaluate = [&](const uint2 ee, const uint32_t h) {
     const uint32_t epos = h_epos[h];
-    const uint32_t g = owner(a, val);
-    if (e.y & SELF_BIT) {
-      const uint32_t i = e.y & ~SELF_BIT;
+    const uint32_t g = owner(a, ee.x);
+    if (ee.y & SELF_BIT) {
+      const uint32_t i = ee.y & ~SELF_BIT;
       const uint32_t c = i * W;
       const uint32_t newf = epos > c;  // UNSET compares greater than any position
       cflag[c] = (uint8_t)(newf | (g << 2));
       a.firstpos[s * a.fcap + i] = epos;
     } else {
-      const uint32_t c = e.y;
+      const uint32_t c = ee.y;
       const uint32_t self = h_self[h];
       const uint32_t fe = epos == c;
       const uint32_t newf = fe && (self == UNSET || (unsigned long long)self * W > c);
       cflag[c] = (uint8_t)(newf | (fe << 1) | (g << 2));
     }
+  };
+#pragma unroll
+  for (int r = 0; r < RC; r++)
+    if (hs[r] != UNSET) evaluate(e[r], hs[r]);
+  for (uint32_t k = n + RC * BT; k < cnt; k += BT) {
+    const uint2 ee = q[k];
+    const uint32_t h = ht_find(h_key, ee.x);
+    if (h != UNSET) evaluate(ee, h);  // UNSET: table overflow, already flagged
   }
 }
 
 // ---- k_count: per-tile counts of the two candidate-level flags, in
-// traversal order, for the list scans
+// traversal order, for the list scans.  One wave per tile, four flag bytes per
+// lane per load.
 __global__ __launch_bounds__(TN) void k_count(LArgs a) {
-  const int s = blockIdx.y;
+  uint32_t bx, s;
+  if (!xcd_block(a, bx, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = bx * NW + (threadIdx.x >> 6);
   if (tile * TN >= F) return;
-  __shared__ uint32_t s_cnt[1 + CSL_MAX_PARTS];
-  const uint32_t n = threadIdx.x;
   const uint32_t W = a.W, P = a.P;
-  if (n < 1 + CSL_MAX_PARTS) s_cnt[n] = 0;
-  __syncthreads();
   const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
-  const uint32_t ncand = nodes_here * W;
-  const uint32_t iters = (ncand + TN - 1) / TN;
-  const size_t cbase = (size_t)s * a.ccap + (size_t)tile * TN * W;
-  for (uint32_t it = 0; it < iters; it++) {
-    const uint32_t k = it * TN + n;
-    const uint32_t fl = k < ncand ? a.cflag[cbase + k] : 0;
-    const uint32_t newf = fl & 1u, fe = (fl >> 1) & 1u, g = fl >> 2;
-    const uint32_t c0 = __popcll(__ballot(newf));
-    if (lane_id() == 0 && c0) atomicAdd(&s_cnt[0], c0);
-    for (uint32_t gg = 0; gg < P; gg++) {
-      const uint32_t cg = __popcll(__ballot(fe && g == gg));
-      if (lane_id() == 0 && cg) atomicAdd(&s_cnt[1 + gg], cg);
+  const uint32_t nbytes = nodes_here * W;
+  // tile bases are multiples of 256 bytes: word loads are aligned
+  const uint32_t* fw = reinterpret_cast<const uint32_t*>(a.cflag + (size_t)s * a.ccap + (size_t)tile * TN * W);
+  uint32_t cnt[1 + CSL_MAX_PARTS];
+#pragma unroll
+  for (int k = 0; k < 1 + CSL_MAX_PARTS; k++) cnt[k] = 0;
+  for (uint32_t o = lane_id() * 4; o < nbytes; o += 256) {
+    uint32_t w = fw[o >> 2];
+    if (o + 4 > nbytes) w &= 0xFFFFFFFFu >> (8 * (o + 4 - nbytes));  // bytes past the tile's candidates
+    cnt[0] += __popc(w & 0x01010101u);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint32_t fl = (w >> (8 * b)) & 0xFFu;
+      const uint32_t fe = (fl >> 1) & 1u, g = fl >> 2;
+#pragma unroll
+      for (int gg = 0; gg < CSL_MAX_PARTS; gg++) cnt[1 + gg] += (fe && g == (uint32_t)gg) ? 1u : 0u;
     }
   }
-  __syncthreads();
-  if (n < 1 + P) a.tcnt[((size_t)s * a.nk + (K_NEWF + n)) * a.tmax + tile] = s_cnt[n];
+#pragma unroll
+  for (int k = 0; k < 1 + CSL_MAX_PARTS; k++) {
+    uint32_t x = cnt[k];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+    cnt[k] = x;
+  }
+  if (lane_id() == 0) {
+#pragma unroll
+    for (int k = 0; k < 1 + CSL_MAX_PARTS; k++)
+      if (k < 1 + (int)P) a.tcnt[((size_t)s * a.nk + (K_NEWF + k)) * a.tmax + tile] = cnt[k];
+  }
 }
 
 // ---- k_emit: stable compaction of everything into the BiPartite lists
 // (bipartite.h:9-26) and of the next frontier.  Positions come from the tile
 // scans (k_scan) plus ballot ranks inside the tile, so every list is in the
 // reference's push order.
+constexpr int EP = 8;  // candidate steps whose flag and id a k_emit thread preloads
+
 __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
-  const int s = blockIdx.y;
+  uint32_t tile, s;
+  if (!xcd_block(a, tile, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
-  const uint32_t tile = blockIdx.x;
   if (tile * TN >= F) return;
   const uint32_t n = threadIdx.x, w = n >> 6;
   const uint32_t W = a.W, P = a.P;
@@ -622,15 +722,37 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   const uint32_t iters = (ncand + TN - 1) / TN;
   const size_t cbase = (size_t)s * a.ccap + (size_t)tile * TN * W;
   const uint32_t nf_cap = m.next_frontier;  // already clamped to capacity
+  // the thread's flags and ids for the first EP steps are requested up front
+  // (independent loads); the loop itself then only ranks and stores
+  uint32_t pf[EP], pv[EP];
+#pragma unroll
+  for (int j = 0; j < EP; j++) {
+    const uint32_t k = j * TN + n;
+    pf[j] = ((uint32_t)j < iters && k < ncand) ? a.cflag[cbase + k] : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < EP; j++) {
+    const uint32_t k = j * TN + n;
+    pv[j] = (pf[j] & 3u) ? a.cand[cbase + k] : 0u;
+  }
   for (uint32_t it = 0; it < iters; it++) {
     const uint32_t k = it * TN + n;
     uint32_t newf = 0, fe = 0, g = 0, val = 0;
-    if (k < ncand) {
-      const uint32_t fl = a.cflag[cbase + k];
+    {
+      uint32_t fl = 0;
+      if (it < (uint32_t)EP) {
+#pragma unroll
+        for (int j = 0; j < EP; j++) {
+          fl = (uint32_t)j == it ? pf[j] : fl;
+          val = (uint32_t)j == it ? pv[j] : val;
+        }
+      } else if (k < ncand) {
+        fl = a.cflag[cbase + k];
+        if (fl & 3u) val = a.cand[cbase + k];
+      }
       newf = fl & 1u;
       fe = (fl >> 1) & 1u;
       g = fl >> 2;
-      if (fl & 3u) val = a.cand[cbase + k];
     }
     const uint32_t b = it & 1;
     const unsigned long long m0 = __ballot(newf);
@@ -751,9 +873,10 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
 // in-node rank of each frontier node inside its own slice, -1 if it was never
 // sampled as a neighbour.
 __global__ __launch_bounds__(TN) void k_selfin(LArgs a) {
-  const int s = blockIdx.y;
+  uint32_t bx, s;
+  if (!xcd_block(a, bx, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
-  const uint32_t i = blockIdx.x * TN + threadIdx.x;
+  const uint32_t i = bx * TN + threadIdx.x;
   if (i >= F) return;
   const uint32_t fp = a.firstpos[s * a.fcap + i];
   long long* ar = a.arena + (size_t)s * a.arena_stride;
@@ -1099,15 +1222,21 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.layer = (uint32_t)l;
     a.fanout = (uint32_t)e->cfg.fanout[l];
     a.W = a.fanout + 1;
+    a.wmagic = ((1ull << 40) + a.W - 1) / a.W;
+    a.S = (uint32_t)S;
     const dim3 blk(TN);
     const unsigned tiles_in = (unsigned)((e->fcap[l] + TN - 1) / TN);
     const size_t ccap_l = (size_t)tiles_in * TN * a.W;
-    const dim3 grid_in(tiles_in, S);
-    const dim3 grid_sample((tiles_in + TPB - 1) / TPB, S);
-    const dim3 grid_scatter((unsigned)((ccap_l + SCT - 1) / SCT), S);
+    const unsigned xg = 8u * (unsigned)((S + 7) / 8);  // see xcd_block()
+    const dim3 grid_in(xg * tiles_in);
+    // small layers are latency-bound: one tile per block; large ones amortise the
+    // bucket-histogram flush over TPB tiles
+    a.tpb = tiles_in > 128 ? TPB : 1;
+    const dim3 grid_sample(xg * ((tiles_in + a.tpb - 1) / a.tpb));
+    const dim3 grid_scatter(xg * (unsigned)((ccap_l + SCT - 1) / SCT));
     unsigned nb_l = (unsigned)((ccap_l + QMEAN - 1) / QMEAN);
     if (nb_l > e->nbmax) nb_l = e->nbmax;
-    const dim3 grid_bucket(nb_l, S);
+    const dim3 grid_bucket(xg * nb_l);
     const size_t lds_hist = (size_t)e->nbmax * sizeof(uint32_t);
     {
       Timed t(e, KN_DEGREE, e->stream);
@@ -1131,11 +1260,11 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     }
     {
       Timed t(e, KN_BUCKET, e->stream);
-      hipLaunchKernelGGL(k_bucket, grid_bucket, blk, 0, e->stream, a);
+      hipLaunchKernelGGL(k_bucket, grid_bucket, dim3(BT), 0, e->stream, a);
     }
     {
       Timed t(e, KN_COUNT, e->stream);
-      hipLaunchKernelGGL(k_count, grid_in, blk, 0, e->stream, a);
+      hipLaunchKernelGGL(k_count, dim3(xg * ((tiles_in + NW - 1) / NW)), blk, 0, e->stream, a);
     }
     {
       Timed t(e, KN_SCAN_B, e->stream);
