@@ -137,13 +137,13 @@ def main():
     eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2,
                       device=local_rank)
     eng.set_nodes(perm)
-    n_batches = (N + B - 1) // B
-    rounds_per_epoch = max(1, n_batches // S)  # full rounds only: every step does S minibatches
+    from cslicer import shard
+    n_rounds, n_batches = shard.rounds_per_epoch(N, B, S)  # full rounds only: every step does S minibatches
 
     def run_round(step):
-        # weak scaling: rank r takes its own rounds; wraps around the epoch
-        ridx = (step * world + rank) % rounds_per_epoch
-        eng.submit_round(ridx * S, B, S, slot=step & 1)
+        # weak scaling: rank r takes its own rounds (cslicer/shard.py); wraps around the epoch
+        first, nb = shard.batches_of_round(shard.round_of(step, rank, world, n_rounds), S)
+        eng.submit_round(first, B, nb, slot=step & 1)
 
     def timed(nsteps, first_step):
         barrier()
@@ -160,11 +160,7 @@ def main():
     for w in range(args.warmup):
         run_round(w)
     eng.sync()
-    dt = timed(args.steps, args.warmup)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(timed(args.steps, args.warmup), dist, "cuda")
 
     # ---- units processed: read the last two rounds' metas (both slots)
     def slot_stats(slot):
@@ -188,11 +184,7 @@ def main():
 
     stats = slot_stats((args.warmup + args.steps - 1) & 1)
     edges_per_round = sum(d["E"] for d in stats)
-    total_edges = edges_per_round * args.steps
-    if dist is not None:
-        t = torch.tensor([float(total_edges)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_edges = float(t.item())
+    total_edges = shard.sum_over_ranks(edges_per_round * args.steps, dist, "cuda")
     iters = args.steps * S * world
     value = total_edges / dt
 

@@ -1,0 +1,59 @@
+"""How minibatches are dealt to GPUs (ranks) and engine streams.
+
+The cslicer path shards by minibatch: there is no exchange step between the
+slicers of different GPUs, so ranks only agree on WHICH minibatches each one
+takes.  Round k of the job is dealt to rank k % world (the same round-robin the
+reference's driver uses for worker threads, cslicer/driver.cpp:69-71, one level
+up); inside a round, minibatch j goes to engine stream j.
+"""
+
+
+def rounds_per_epoch(num_nodes, batch_size, streams):
+    """Full rounds in one pass over the node order (a short tail round is dealt
+    separately by `tail_round`)."""
+    n_batches = (num_nodes + batch_size - 1) // batch_size
+    return n_batches // streams, n_batches
+
+
+def round_of(step, rank, world, n_rounds):
+    """Global round index rank `rank` slices at its local step `step` (wraps
+    around the epoch so a weak-scaling run of any length stays in range)."""
+    if n_rounds < 1:
+        raise ValueError("need at least one full round")
+    return (step * world + rank) % n_rounds
+
+
+def batches_of_round(round_idx, streams):
+    """First minibatch index and count of a full round."""
+    return round_idx * streams, streams
+
+
+def epoch_plan(num_nodes, batch_size, streams, world):
+    """Every (rank, first_batch, n_batches) of one epoch, each minibatch exactly once."""
+    full, n_batches = rounds_per_epoch(num_nodes, batch_size, streams)
+    plan = []
+    for r in range(full):
+        plan.append((r % world, r * streams, streams))
+    tail = n_batches - full * streams
+    if tail:
+        plan.append((full % world, full * streams, tail))
+    return plan
+
+
+def max_over_ranks(seconds, dist=None, device=None):
+    """The job's wall time is the slowest rank's (bench.py contract)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(seconds)
+    import torch
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, dist=None, device=None):
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

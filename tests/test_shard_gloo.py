@@ -1,0 +1,79 @@
+"""Multi-rank host logic on CPU: two processes, torch.distributed gloo, 127.0.0.1.
+Checks that the minibatch sharding bench.py uses deals every minibatch of an
+epoch to exactly one rank, and that the timing/unit reductions agree on all ranks."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "occ-gnn_amd"))
+    from cslicer import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, B, S = 10_000, 64, 8
+    plan = shard.epoch_plan(N, B, S, world)
+    mine = [(f, n) for (r, f, n) in plan if r == rank]
+    got = sorted(b for f, n in mine for b in range(f, f + n))
+    # exchange: every rank learns every rank's minibatches
+    gathered = [None] * world
+    dist.all_gather_object(gathered, got)
+    everything = sorted(b for g in gathered for b in g)
+    n_batches = (N + B - 1) // B
+    ok_cover = everything == list(range(n_batches))
+    # weak-scaling steps: ranks never collide within a step
+    n_rounds, _ = shard.rounds_per_epoch(N, B, S)
+    steps = [shard.round_of(k, rank, world, n_rounds) for k in range(5)]
+    all_steps = [None] * world
+    dist.all_gather_object(all_steps, steps)
+    ok_disjoint = all(len({all_steps[r][k] for r in range(world)}) == world for k in range(5))
+    t = shard.max_over_ranks(1.0 + rank, dist)
+    e = shard.sum_over_ranks(100.0 * (rank + 1), dist)
+    dist.barrier()
+    q.put((rank, ok_cover, ok_disjoint, t, e))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_cover, ok_disjoint, t, e in res:
+        assert ok_cover, "rank %d: epoch plan does not cover every minibatch exactly once" % rank
+        assert ok_disjoint
+        assert t == 2.0           # max over ranks of (1.0, 2.0)
+        assert e == 300.0         # sum over ranks
+
+
+def test_epoch_plan_single_rank_and_tail():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "occ-gnn_amd"))
+    from cslicer import shard
+    plan = shard.epoch_plan(1000, 100, 4, 1)           # 10 minibatches: 2 full rounds + tail of 2
+    assert plan == [(0, 0, 4), (0, 4, 4), (0, 8, 2)]
+    plan3 = shard.epoch_plan(1000, 100, 4, 3)
+    assert [r for r, _, _ in plan3] == [0, 1, 2]
+    assert shard.round_of(3, 1, 4, 5) == (3 * 4 + 1) % 5
