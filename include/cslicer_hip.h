@@ -154,7 +154,7 @@ int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t lay
                         const int64_t** out);
 /* device pointer of the frontier entering `layer` (0..n_layers; n_layers = the
  * nodes whose features the model reads); uint32 ids; length in meta */
-int csl_frontier_device_ptr(csl_engine* e, int32_t stream, int32_t layer, const uint32_t** out);
+int csl_frontier_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, const uint32_t** out);
 int64_t csl_copy_frontier(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int64_t* dst,
                           int64_t cap);
 

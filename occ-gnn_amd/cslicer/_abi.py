@@ -107,7 +107,7 @@ def load():
     L.csl_copy_list.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, p64, C.c_int64]
     L.csl_copy_list.restype = C.c_int64
     L.csl_list_device_ptr.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
-    L.csl_frontier_device_ptr.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.csl_frontier_device_ptr.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.csl_copy_frontier.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, p64, C.c_int64]
     L.csl_copy_frontier.restype = C.c_int64
     L.csl_hip_stream.argtypes = [vp, C.POINTER(vp)]
@@ -234,9 +234,9 @@ class Engine:
         _check(load().csl_list_device_ptr(self._h, slot, stream, layer, kind, C.byref(p)))
         return p.value
 
-    def frontier_device_ptr(self, layer, stream=0):
+    def frontier_device_ptr(self, layer, stream=0, slot=0):
         p = C.c_void_p()
-        _check(load().csl_frontier_device_ptr(self._h, stream, layer, C.byref(p)))
+        _check(load().csl_frontier_device_ptr(self._h, slot, stream, layer, C.byref(p)))
         return p.value
 
     def hip_stream(self):

@@ -1175,8 +1175,8 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
   {
     Timed t(e, KN_SEEDS, e->stream);
     dim3 grid((unsigned)((e->fcap[0] + TN - 1) / TN), S);
-    hipLaunchKernelGGL(k_seeds, grid, dim3(TN), 0, e->stream, nodes_dev, dd, e->fr[0], e->fcap[0], e->fsize, meta,
-                       e->rngpos, e->N, L);
+    hipLaunchKernelGGL(k_seeds, grid, dim3(TN), 0, e->stream, nodes_dev, dd,
+                       e->fr[0] + (size_t)slot * S * e->fcap[0], e->fcap[0], e->fsize, meta, e->rngpos, e->N, L);
   }
   for (int l = 0; l < L; l++) {
     LArgs a;
@@ -1192,8 +1192,8 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.gen_hi = e->gen_hi;
     a.rngpos = e->rngpos;
     a.rngbase = e->rngbase;
-    a.fr_in = e->fr[l];
-    a.fr_out = e->fr[l + 1];
+    a.fr_in = e->fr[l] + (size_t)slot * S * e->fcap[l];
+    a.fr_out = e->fr[l + 1] + (size_t)slot * S * e->fcap[l + 1];
     a.fr_in_stride = e->fcap[l];
     a.fr_out_stride = e->fcap[l + 1];
     a.fr_out_cap = (uint32_t)e->fcap[l + 1];
@@ -1385,7 +1385,7 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   e->tmax = (uint32_t)((e->fcap_max + TN - 1) / TN);
   e->nk = (uint32_t)NKINDS(P);
   // ---- per-stream scratch
-  for (int l = 0; l <= L; l++) DMALLOC(e->fr[l], (size_t)S * e->fcap[l]);
+  for (int l = 0; l <= L; l++) DMALLOC(e->fr[l], (size_t)e->slots * S * e->fcap[l]);  // [slot][S][fcap]
   DMALLOC(e->ninfo, (size_t)S * e->fcap_max);
   DMALLOC(e->hasedge, (size_t)S * e->fcap_max);
   DMALLOC(e->selfpos, (size_t)S * e->fcap_max);
@@ -1642,10 +1642,11 @@ int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t lay
   return 0;
 }
 
-int csl_frontier_device_ptr(csl_engine* e, int32_t stream, int32_t layer, const uint32_t** out) {
+int csl_frontier_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, const uint32_t** out) {
   if (!e || !out) return fail(CSL_E_INVALID, "null argument");
-  if (stream < 0 || stream >= e->S || layer < 0 || layer > e->L) return fail(CSL_E_INVALID, "index out of range");
-  *out = e->fr[layer] + (size_t)stream * e->fcap[layer];
+  if (slot < 0 || slot >= e->slots || stream < 0 || stream >= e->S || layer < 0 || layer > e->L)
+    return fail(CSL_E_INVALID, "index out of range");
+  *out = e->fr[layer] + ((size_t)slot * e->S + stream) * e->fcap[layer];
   return 0;
 }
 
@@ -1661,8 +1662,8 @@ int64_t csl_copy_frontier(csl_engine* e, int32_t slot, int32_t stream, int32_t l
   if (n > cap) return fail(CSL_E_INVALID, "destination too small: need %lld", (long long)n);
   std::vector<uint32_t> tmp((size_t)n);
   if (n) {
-    hipError_t er = hipMemcpy(tmp.data(), e->fr[layer] + (size_t)stream * e->fcap[layer], sizeof(uint32_t) * (size_t)n,
-                              hipMemcpyDeviceToHost);
+    hipError_t er = hipMemcpy(tmp.data(), e->fr[layer] + ((size_t)slot * e->S + stream) * e->fcap[layer],
+                              sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost);
     if (er != hipSuccess) return fail(CSL_E_HIP, "hipMemcpy failed: %s", hipGetErrorString(er));
   }
   for (int64_t i = 0; i < n; i++) dst[i] = (int64_t)tmp[(size_t)i];

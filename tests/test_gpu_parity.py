@@ -161,3 +161,126 @@ def test_hub_graph_many_duplicates_per_bucket(abi, orc):
         want = orc.Oracle(indptr, indices).sample(perm[s * 512:(s + 1) * 512])
         assert_same_sample(e.sample_dict(s), want, what="hub stream %d" % s)
     e.close()
+
+
+def _check_sample_properties(d, indptr, indices, P, fan, seeds):
+    """Size-independent invariants of one sample (any graph size)."""
+    frontier = d["frontier"]
+    np.testing.assert_array_equal(frontier[0], seeds)
+    for l, f in enumerate(fan):
+        fr, nxt = frontier[l], frontier[l + 1]
+        assert len(np.unique(nxt)) == len(nxt), "next frontier has duplicates"
+        assert np.isin(fr, nxt).all(), "frontier must survive into the next one (self entries)"
+        assert nxt[0] == fr[0]  # the first candidate of the traversal is the first node itself
+        tot_self = 0
+        all_in = []
+        for g in range(P):
+            bp = d["layers"][l][g]
+            ins, outs = bp["in_nodes"], bp["out_nodes"]
+            assert len(np.unique(ins)) == len(ins)
+            assert (ins % P == g).all(), "slice g holds edges whose source is owned by g"
+            assert np.isin(ins, nxt).all()
+            assert np.isin(outs, fr).all() and len(np.unique(outs)) == len(outs)
+            assert (bp["indptr"] == 1).all() and len(bp["indptr"]) == len(outs) and len(bp["indices"]) == 0
+            own = bp["owned_out_nodes"]
+            assert ((own >= 0) & (own < len(outs))).all() and (outs[own] % P == g).all()
+            si, so = bp["self_ids_in"], bp["self_ids_out"]
+            assert len(si) == len(so)
+            tot_self += len(si)
+            assert ((si >= -1) & (si < max(len(ins), 1))).all() and ((so >= -1) & (so < max(len(outs), 1))).all()
+            selfnodes = fr[fr % P == g]
+            assert len(selfnodes) == len(si)
+            ok = so >= 0
+            np.testing.assert_array_equal(outs[so[ok]], selfnodes[ok])
+            ok = si >= 0
+            np.testing.assert_array_equal(ins[si[ok]], selfnodes[ok])
+            fo = bp["from_ids"][g]
+            assert ((fo >= 0) & (fo < len(outs))).all() and (outs[fo] % P != g).all()
+            to = bp["to_ids"][g]
+            assert ((to >= -1) & (to < max(len(outs), 1))).all()
+            all_in.append(ins)
+        assert tot_self == len(fr)
+        # every in-node is a real neighbour of some frontier node
+        some = np.concatenate(all_in)[:2000]
+        nbr_of_fr = np.unique(np.concatenate([indices[indptr[v]:indptr[v + 1]] for v in fr[:50000]]))
+        if len(fr) <= 50000:
+            assert np.isin(some, nbr_of_fr).all()
+
+
+def test_full_size_products_like(abi, orc):
+    """BASELINE configs[1] shape: N=2,449,029, mean degree 50.5, fanout 15/10/5,
+    batch 1024, 4 parts.  Bit-exact against the oracle for 3 minibatches, invariants
+    on every stream, and run-to-run determinism."""
+    from cslicer import l0
+    n, _, _, _ = l0.PRESETS["products-like"]
+    indptr, indices = l0.synth_graph(n, 50.5, seed=0)
+    perm = np.random.default_rng(1).permutation(n)
+    fan, P, B, S = (15, 10, 5), 4, 1024, 8
+    e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2)
+    e.set_nodes(perm)
+    e.submit_round(0, B, S, slot=0)
+    e.submit_round(S, B, S, slot=1)
+    got0 = [e.sample_dict(s, slot=0) for s in range(S)]
+    for s in range(S):
+        _check_sample_properties(got0[s], indptr, indices, P, fan, perm[s * B:(s + 1) * B])
+    for s in range(3):
+        o = orc.Oracle(indptr, indices, n_parts=P, fanouts=fan)
+        want0 = o.sample(perm[s * B:(s + 1) * B])
+        assert_same_sample(got0[s], want0, what="full-size stream %d round 0" % s, check_traversal=False)
+        want1 = o.sample(perm[(S + s) * B:(S + s + 1) * B])   # same worker, next round: rng carries over
+        assert_same_sample(e.sample_dict(s, slot=1), want1, what="full-size stream %d round 1" % s,
+                           check_traversal=False)
+    e.close()
+    # determinism: a fresh engine reproduces the round bit for bit
+    e2 = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S)
+    e2.set_nodes(perm)
+    e2.submit_round(0, B, S)
+    for s in (0, S - 1):
+        assert_same_sample(e2.sample_dict(s), got0[s], what="determinism stream %d" % s, check_traversal=False)
+    e2.close()
+
+
+def test_frontend_module_end_to_end(abi, orc, tmp_path, monkeypatch):
+    """The pybind-surface mirror: cslicer(name, queue, workers, epochs, batch) ->
+    getNoSamples()/getSample() over an L0 directory, two epochs, libstdc++-style
+    shuffle, against one oracle per worker."""
+    import ctypes
+    import cslicer as mod
+    from cslicer import l0
+    from cslicer.frontend import epoch_shuffle
+    n = 3000
+    indptr, indices = l0.synth_graph(n, 14.0, seed=21)
+    l0.write_l0(str(tmp_path / "toy"), indptr, indices)
+    monkeypatch.setenv("CSLICER_DATA_ROOT", str(tmp_path) + "/")
+    libc = ctypes.CDLL(None)
+    libc.srand(1)   # glibc's state when rand() was never seeded (WorkerPool.cpp:40)
+    S, B, epochs = 3, 256, 2
+    csl = mod.cslicer("toy", 16, S, epochs, B)
+    ns = csl.getNoSamples()
+    assert ns == ((n - 1) // B + 1) * epochs
+    samples = [csl.getSample() for _ in range(ns)]
+    with pytest.raises(RuntimeError):
+        csl.getSample()
+    csl.close()
+    # replay: same shuffles, batch b of an epoch -> worker b % S
+    libc.srand(1)
+    nodes = np.arange(n, dtype=np.int64)
+    oracles = [orc.Oracle(indptr, indices) for _ in range(S)]
+    k = 0
+    for ep in range(epochs):
+        epoch_shuffle(nodes)
+        nb = (n - 1) // B + 1
+        for b in range(nb):
+            want = oracles[b % S].sample(nodes[b * B:(b + 1) * B])
+            s = samples[k]
+            k += 1
+            assert len(s.layers) == 3 and len(s.layers[0]) == 4
+            for l in range(3):
+                for g in range(4):
+                    bp, wb = s.layers[l][g], want["layers"][l][g]
+                    assert bp.gpu_id == g
+                    for name in ("in_nodes", "indptr", "out_nodes", "owned_out_nodes", "indices",
+                                 "self_ids_in", "self_ids_out"):
+                        assert getattr(bp, name) == wb[name].tolist(), (ep, b, l, g, name)
+                    assert bp.from_ids == [x.tolist() for x in wb["from_ids"]]
+                    assert bp.to_ids == [x.tolist() for x in wb["to_ids"]]
