@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=64, help="S: minibatches per round")
+    ap.add_argument("--streams", type=int, default=128, help="S: minibatches per round")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--fanout", type=str, default="15,10,5")
     ap.add_argument("--parts", type=int, default=4)
@@ -82,14 +82,15 @@ def path_bytes_reference_types(meta_layers, P):
     return B
 
 
-def kernel_bytes_device_layout(name, m, P):
+def kernel_bytes_device_layout(name, m, P, layer=0, last=False):
     """Algorithmic bytes one launch of `name` must move for one minibatch-layer,
     in the engine's own HBM layout (u32 ids internally, int64 exported lists).
     Stated per term in DESIGN.md section 5."""
     F, E, D, U, C = m["F"], m["E"], m["D"], m["U"], m["C"]
     Q = E + F  # bucket queue entries: one per real candidate
     if name == "k_degree":
-        return F * (4 + 8 + 8)                 # id, rowinfo gather, ninfo store
+        # layer 0: id, rowinfo gather, ninfo store; later layers read the ninfo k_emit prepared
+        return F * (4 + 8 + 8) if layer == 0 else F * 8
     if name == "k_sample":
         # ids + ninfo, rng words, neighbour gather, candidate + flag store, part mask
         return F * (4 + 8) + D * 4 + E * 4 + C * (4 + 1) + F * 4
@@ -100,8 +101,10 @@ def kernel_bytes_device_layout(name, m, P):
     if name == "k_count":
         return C * 1
     if name == "k_emit":
+        # flags, ids of flagged candidates, next frontier, in_nodes + ranks, node lists,
+        # and (not on the last layer) the next layer's rowinfo gather + ninfo store
         return (C * 1 + (U + m["in_total"]) * 4 + U * 4 + m["in_total"] * (8 + 4)
-                + F * (4 + 4) + m["node_lists"] * 8 + F * 4)
+                + F * (4 + 4) + m["node_lists"] * 8 + F * 4 + (0 if last else U * 16))
     if name == "k_selfin":
         return F * (4 + 4 + 4 + 8)
     return 0
@@ -230,7 +233,8 @@ def main():
                 if n == 0 or name in ("k_seeds", "k_scan_need", "k_scan_lists", "k_scan_buckets", "k_mt19937_fill"):
                     per_kernel[name] = {"ms_total": ms, "launches": n}
                     continue
-                nbytes = sum(kernel_bytes_device_layout(name, d, P) for d in stats2) * args.steps
+                nbytes = sum(kernel_bytes_device_layout(name, d, P, l, l == len(stats2) - 1)
+                             for l, d in enumerate(stats2)) * args.steps
                 per_kernel[name] = {"ms_total": ms, "launches": n, "avg_us": 1e3 * ms / n,
                                     "alg_bytes_per_launch": nbytes / n,
                                     "achieved_GBs": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None}

@@ -116,6 +116,7 @@ struct LArgs {
   unsigned long long wmagic;  // ceil(2^40 / W): exact c / W for c < 2^31, W < 512
   uint32_t S;
   uint32_t tpb;               // frontier tiles per k_sample block
+  uint32_t last;              // 1 on the final layer (no next frontier to prepare)
 };
 
 constexpr uint32_t SELF_BIT = 0x80000000u;
@@ -201,10 +202,14 @@ __global__ __launch_bounds__(TN) void k_degree(LArgs a) {
   const uint32_t i = tile * TN + threadIdx.x;
   uint32_t need = 0, ne = 0;
   if (i < F) {
-    const uint32_t v = a.fr_in[s * a.fr_in_stride + i];
-    const unsigned long long ri = a.rowinfo[v];
+    unsigned long long ri;
+    if (a.layer == 0) {
+      ri = a.rowinfo[a.fr_in[s * a.fr_in_stride + i]];
+      a.ninfo[s * a.fcap + i] = ri;
+    } else {
+      ri = a.ninfo[s * a.fcap + i];  // gathered by the previous layer's k_emit
+    }
     const uint32_t deg = (uint32_t)(ri & DEG_MASK);
-    a.ninfo[s * a.fcap + i] = ri;
     need = deg >= a.fanout;
     ne = deg < a.fanout ? deg : a.fanout;
   }
@@ -502,9 +507,12 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
 
 // ---- k_scatter: partitions the candidate stream into the dedup buckets.
 // Self entries carry the node's frontier index, edge entries their position;
-// holes (short rows, sampled self loops) never reach a bucket.
+// holes (short rows, sampled self loops) never reach a bucket.  A block counting-
+// sorts its SCT candidates by bucket in LDS first, so the pairs of one bucket
+// leave as one contiguous run (random 8-B stores run at ~90 G/s on this chip,
+// runs of 8-16 at 400-600 G/s: profiles/microbench/RESULTS.md).
 __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // [2*nb]: histogram, base
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // hist[nb] loff[nb] gbase[nb] staged[2*SCT]
   uint32_t bx, s;
   if (!xcd_block(a, bx, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
@@ -514,13 +522,17 @@ __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
   if (base >= C) return;
   const uint32_t nb = a.nbk[s];
   uint32_t* s_hist = s_dyn;
-  uint32_t* s_base = s_dyn + nb;
+  uint32_t* s_loff = s_dyn + nb;
+  uint32_t* s_gbase = s_dyn + 2 * nb;
+  uint2* s_stage = reinterpret_cast<uint2*>(s_dyn + ((3 * nb + 1) & ~1u));
+  __shared__ uint32_t s_part[TN];
   const uint32_t n = threadIdx.x;
   for (uint32_t b = n; b < nb; b += TN) s_hist[b] = 0;
   __syncthreads();
   const uint32_t* cand = a.cand + (size_t)s * a.ccap + base;
   const uint32_t cnt = (C - base) < (unsigned long long)SCT ? (uint32_t)(C - base) : (uint32_t)SCT;
   constexpr int CU = 8;
+  // pass A: bucket histogram of this block's candidates
   for (uint32_t k0 = n; k0 < cnt; k0 += TN * CU) {
     uint32_t v[CU];
 #pragma unroll
@@ -530,14 +542,44 @@ __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
       if (v[u] != UNSET) atomicAdd(&s_hist[bucket_of(v[u], nb)], 1u);
   }
   __syncthreads();
-  uint32_t* cur = a.bcur + (size_t)s * a.nbmax;
-  for (uint32_t b = n; b < nb; b += TN) {
-    const uint32_t h = s_hist[b];
-    s_base[b] = h ? atomicAdd(&cur[b], h) : 0;
-    s_hist[b] = 0;
+  // exclusive scan of the histogram (LDS offsets) + one global reservation per bucket
+  const uint32_t chunk = (nb + TN - 1) / TN;
+  const uint32_t b_lo = n * chunk < nb ? n * chunk : nb;
+  const uint32_t b_hi = b_lo + chunk < nb ? b_lo + chunk : nb;
+  uint32_t part = 0;
+  for (uint32_t b = b_lo; b < b_hi; b++) part += s_hist[b];
+  s_part[n] = part;
+  __syncthreads();
+  if (n < 64) {
+    // one wave scans the 256 partial sums, 4 per lane
+    uint32_t p4[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      p4[j] = s_part[n * 4 + j];
+      sum += p4[j];
+    }
+    uint32_t tot;
+    uint32_t ex = wave_excl_scan(sum, tot);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      s_part[n * 4 + j] = ex;
+      ex += p4[j];
+    }
   }
   __syncthreads();
-  uint2* q = a.queue + (size_t)s * a.ccap;
+  uint32_t* cur = a.bcur + (size_t)s * a.nbmax;
+  {
+    uint32_t run = s_part[n];
+    for (uint32_t b = b_lo; b < b_hi; b++) {
+      const uint32_t h = s_hist[b];
+      s_loff[b] = run;
+      s_gbase[b] = h ? atomicAdd(&cur[b], h) : 0;
+      s_hist[b] = 0;
+      run += h;
+    }
+  }
+  __syncthreads();
+  // pass B: place every pair at its sorted LDS position
   for (uint32_t k0 = n; k0 < cnt; k0 += TN * CU) {
     uint32_t v[CU];
 #pragma unroll
@@ -548,9 +590,18 @@ __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
       const uint32_t c = (uint32_t)base + k0 + u * TN;
       const uint32_t i = div_w(a, c);
       const uint32_t b = bucket_of(v[u], nb);
-      const uint32_t p = s_base[b] + atomicAdd(&s_hist[b], 1u);
-      q[p] = make_uint2(v[u], c == i * W ? (SELF_BIT | i) : c);
+      const uint32_t p = s_loff[b] + atomicAdd(&s_hist[b], 1u);
+      s_stage[p] = make_uint2(v[u], c == i * W ? (SELF_BIT | i) : c);
     }
+  }
+  __syncthreads();
+  // write-out: consecutive threads, consecutive pairs of a bucket, consecutive addresses
+  uint2* q = a.queue + (size_t)s * a.ccap;
+  const uint32_t staged = s_loff[nb - 1] + s_hist[nb - 1];  // pass B left every bucket's count in s_hist
+  for (uint32_t k = n; k < staged; k += TN) {
+    const uint2 e = s_stage[k];
+    const uint32_t b = bucket_of(e.x, nb);
+    q[s_gbase[b] + (k - s_loff[b])] = e;
   }
 }
 
@@ -769,7 +820,11 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       uint32_t p = s_run[0] + r0;
       for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][0];
       p += TB(K_NEWF);
-      if (p < nf_cap) a.fr_out[s * a.fr_out_stride + p] = val;
+      if (p < nf_cap) {
+        a.fr_out[s * a.fr_out_stride + p] = val;
+        // the next layer's row lookup rides on this pass (slicer.cpp:8-9)
+        if (!a.last) a.ninfo[s * a.fcap + p] = a.rowinfo[val];
+      }
     }
     if (fe) {
       uint32_t p = s_run[1 + g] + rE;
@@ -1011,6 +1066,7 @@ struct csl_engine {
   uint32_t* bcnt = nullptr;
   uint32_t* bcur = nullptr;
   uint32_t nbmax = 0;
+  size_t scatter_lds = 0;
   uint32_t* tcnt = nullptr;
   uint32_t* fsize = nullptr;
   // results
@@ -1224,6 +1280,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.W = a.fanout + 1;
     a.wmagic = ((1ull << 40) + a.W - 1) / a.W;
     a.S = (uint32_t)S;
+    a.last = l == L - 1 ? 1u : 0u;
     const dim3 blk(TN);
     const unsigned tiles_in = (unsigned)((e->fcap[l] + TN - 1) / TN);
     const size_t ccap_l = (size_t)tiles_in * TN * a.W;
@@ -1256,7 +1313,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     }
     {
       Timed t(e, KN_SCATTER, e->stream);
-      hipLaunchKernelGGL(k_scatter, grid_scatter, blk, 2 * lds_hist, e->stream, a);
+      hipLaunchKernelGGL(k_scatter, grid_scatter, blk, e->scatter_lds, e->stream, a);
     }
     {
       Timed t(e, KN_BUCKET, e->stream);
@@ -1399,6 +1456,9 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   if (e->nbmax > 8192)
     return fail(CSL_E_INVALID, "a layer may hold %zu candidates per minibatch; this build supports %d",
                 e->ccap_max, 8192 * QMEAN);
+  e->scatter_lds = (((size_t)3 * e->nbmax + 1) & ~(size_t)1) * sizeof(uint32_t) + (size_t)SCT * sizeof(uint2);
+  if (e->scatter_lds > 150 * 1024) return fail(CSL_E_INVALID, "k_scatter needs %zu bytes of LDS", e->scatter_lds);
+  HIPCHECK(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->scatter_lds));
   DMALLOC(e->nbk, (size_t)S);
   DMALLOC(e->bcnt, (size_t)S * (e->nbmax + 1));
   DMALLOC(e->bcur, (size_t)S * e->nbmax);
