@@ -246,6 +246,20 @@ def main():
                 "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_us": d["avg_us"], "alg_bytes_per_launch": d["alg_bytes_per_launch"],
             }
+            # HBM traffic of the same kernel from the committed rocprofv3 PMC passes
+            # (profiles/<LATEST>/pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
+            # command at the same stream count; KiB, raw: MI355X_MICROARCH.md's x2 FETCH correction
+            # applies to wide coalesced streams only, this kernel's reads are narrow)
+            try:
+                latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
+                pmc = json.load(open(os.path.join(ROOT, "profiles", latest, "pmc.json")))
+                bj = json.loads(open(os.path.join(ROOT, "profiles", latest, "bench_fetch.json")).read())
+                if bj["config"]["streams"] == S and dom in pmc["calls"]:
+                    calls = pmc["calls"][dom]
+                    out["roofline"]["traffic"] = 1024.0 * (pmc["fetch_KiB_sum"][dom] + pmc["write_KiB_sum"][dom]) / calls
+                    out["roofline"]["traffic_source"] = "profiles/%s/pmc.json (FETCH_SIZE raw + WRITE_SIZE)" % latest
+            except Exception:
+                pass
             out["kernels"] = per_kernel
             out["timing_pass_ms_per_step"] = 1e3 * t_ev / args.steps
         # whole path against the HBM roof, SURVEY 8(d) byte formula (reference data types)
