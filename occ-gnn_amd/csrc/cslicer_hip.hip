@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "cslicer_hip.h"
@@ -1031,6 +1032,8 @@ struct csl_engine {
   size_t E;
   hipStream_t stream = nullptr, rng_stream = nullptr;
   hipEvent_t rng_event = nullptr;
+  std::vector<hipEvent_t> slot_event;  // recorded after the round that fills a result slot
+  std::vector<char> slot_pending;
   // graph
   unsigned long long* rowinfo = nullptr;
   uint32_t* indices = nullptr;
@@ -1338,6 +1341,8 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
   }
   HIPCHECK(hipGetLastError());
   for (int s = 0; s < n_batches && s < S; s++) e->pos_ub[s] += e->worst_draws;
+  HIPCHECK(hipEventRecord(e->slot_event[slot], e->stream));
+  e->slot_pending[slot] = 1;
   e->dirty = true;
   e->meta_valid[slot] = 0;
   return 0;
@@ -1372,6 +1377,7 @@ void csl_destroy(csl_engine* e) {
     if (e->arena[l]) hipFree(e->arena[l]);
   if (e->desc_host) hipHostFree(e->desc_host);
   if (e->rng_event) hipEventDestroy(e->rng_event);
+  for (auto ev : e->slot_event) hipEventDestroy(ev);
   if (e->stream) hipStreamDestroy(e->stream);
   if (e->rng_stream) hipStreamDestroy(e->rng_stream);
   delete e;
@@ -1497,6 +1503,9 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   HIPCHECK(hipHostMalloc((void**)&e->desc_host, sizeof(BatchDesc) * e->slots * S, hipHostMallocDefault));
   e->meta_host.resize((size_t)e->slots * S);
   e->meta_valid.assign(e->slots, 0);
+  e->slot_event.resize(e->slots);
+  e->slot_pending.assign(e->slots, 0);
+  for (int k = 0; k < e->slots; k++) HIPCHECK(hipEventCreateWithFlags(&e->slot_event[k], hipEventDisableTiming));
   // ---- rng
   const uint32_t lg = cfg->rng_ring_log2 ? cfg->rng_ring_log2 : 26;
   e->ring_words = 1ull << lg;
@@ -1639,15 +1648,17 @@ int csl_sync(csl_engine* e) {
   HIPCHECK(hipStreamSynchronize(e->stream));
   HIPCHECK(hipStreamSynchronize(e->rng_stream));
   e->dirty = false;
+  std::fill(e->slot_pending.begin(), e->slot_pending.end(), 0);
   int r = collect_timing(e);
   if (r) return r;
   return refresh_positions(e);
 }
 
 static int load_meta(csl_engine* e, int32_t slot) {
-  if (e->dirty) {
-    int r = csl_sync(e);
-    if (r) return r;
+  // wait for the round that filled THIS slot only; later rounds keep running
+  if (e->slot_pending[slot]) {
+    HIPCHECK(hipEventSynchronize(e->slot_event[slot]));
+    e->slot_pending[slot] = 0;
   }
   if (!e->meta_valid[slot]) {
     HIPCHECK(hipMemcpy(e->meta_host.data() + (size_t)slot * e->S, e->meta + (size_t)slot * e->S,

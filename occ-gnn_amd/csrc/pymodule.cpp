@@ -1,0 +1,354 @@
+// pymodule.cpp -- native host side of the drop-in: the pybind11 module `cslicer`
+// with the reference module's exact surface (cslicer/pyfrontend.cpp:116-148),
+// over the C ABI of the HIP engine (include/cslicer_hip.h).
+//
+//   reference                         here
+//   Dataset (dataset.cpp:8-113)       L0Dataset: same files, checksums enforced
+//   WorkerPool::run (WorkerPool.cpp)  Producer thread: epoch shuffle with the same
+//                                     std::random_shuffle call, rounds of S
+//                                     minibatches submitted to the GPU
+//   Slicer workers (slicer.cpp)       engine streams (one mt19937(5489) each)
+//   ConQueue (util/conqueue.h)        ReadyQueue: bounded, blocking, GIL released
+//   PySample/PyBipartite              same structs, same def_readwrite members
+//
+// The producer keeps two rounds in flight (two result slots): while the GPU
+// slices round r+1 the host copies round r's lists into PySample objects.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <fstream>
+#include <mutex>
+#include <queue>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "cslicer_hip.h"
+
+namespace py = pybind11;
+
+namespace {
+
+const char* kDefaultRoot = "/data/sandeep/";  // pyfrontend.cpp:24
+
+// ---- PyBipartite / PySample: pybipartite.h:10-47, same members, same types
+struct PyBipartite {
+  std::vector<long> in_nodes, indptr, out_nodes, owned_out_nodes, indices;
+  std::vector<std::vector<long>> from_ids, to_ids;
+  std::vector<long> self_ids_in, self_ids_out;
+  int gpu_id = -1;
+};
+
+struct PySample {
+  std::vector<std::vector<PyBipartite*>*> layers;
+  long in_nodes = 0, out_nodes = 0;  // pybipartite.cpp:57-62 (not exported there either)
+  ~PySample() {
+    for (auto l : layers) {
+      for (auto b : *l) delete b;
+      delete l;
+    }
+  }
+};
+
+PySample* empty_sample(int n_layers, int n_parts) {
+  PySample* s = new PySample();
+  for (int l = 0; l < n_layers; l++) {
+    auto row = new std::vector<PyBipartite*>();
+    for (int g = 0; g < n_parts; g++) {
+      auto b = new PyBipartite();
+      b->gpu_id = g;
+      b->from_ids.resize(n_parts);
+      b->to_ids.resize(n_parts);
+      row->push_back(b);
+    }
+    s->layers.push_back(row);
+  }
+  return s;
+}
+
+// ---- Dataset: dataset.cpp:8-113 (graph part; features/labels/partition map are
+// loaded by the reference but never used by the slicer)
+struct L0Dataset {
+  long num_nodes = -1, num_edges = -1, csum_offsets = 0, csum_edges = 0;
+  std::vector<long> indptr, indices;
+  explicit L0Dataset(const std::string& dir) {
+    std::ifstream meta(dir + "/meta.txt");
+    if (!meta) throw std::runtime_error("cslicer: cannot open " + dir + "/meta.txt");
+    std::string line;
+    while (std::getline(meta, line)) {
+      if (meta.eof()) break;  // dataset.cpp:75: an unterminated last line is dropped
+      auto eq = line.find('=');
+      if (eq == std::string::npos) continue;
+      const std::string name = line.substr(0, eq);
+      const long val = std::stoll(line.substr(eq + 1));
+      if (name == "num_nodes") num_nodes = val;
+      if (name == "num_edges") num_edges = val;
+      if (name == "csum_offsets") csum_offsets = val;
+      if (name == "csum_edges") csum_edges = val;
+    }
+    if (num_nodes < 1 || num_edges < 0) throw std::runtime_error("cslicer: meta.txt lacks num_nodes/num_edges");
+    indptr.resize(num_nodes + 1);
+    indices.resize(num_edges);
+    read_all(dir + "/indptr.bin", indptr);
+    read_all(dir + "/indices.bin", indices);
+    long s = 0;
+    for (long v : indptr) s += v;
+    if (s != csum_offsets) throw std::runtime_error("cslicer: indptr checksum mismatch (dataset.cpp:27)");
+    s = 0;
+    for (long v : indices) s += v;
+    if (s != csum_edges) throw std::runtime_error("cslicer: indices checksum mismatch (dataset.cpp:35)");
+  }
+  static void read_all(const std::string& path, std::vector<long>& dst) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cslicer: cannot open " + path);
+    f.read(reinterpret_cast<char*>(dst.data()), (std::streamsize)(dst.size() * sizeof(long)));
+    if ((size_t)f.gcount() != dst.size() * sizeof(long)) throw std::runtime_error("cslicer: short read of " + path);
+  }
+};
+
+// ---- ConQueue<PySample*>: util/conqueue.h:10-63, plus a close() so that the
+// destructor cannot deadlock (the reference's ~CSlicer joins a producer that may
+// be blocked on a full queue, pyfrontend.cpp:85-88)
+class ReadyQueue {
+  size_t max_size_;
+  std::queue<PySample*> q_;
+  std::mutex m_;
+  std::condition_variable has_space_, not_empty_;
+  bool closed_ = false;
+  std::string error_;
+
+ public:
+  explicit ReadyQueue(size_t n) : max_size_(n) {}
+  bool push(PySample* s) {
+    std::unique_lock<std::mutex> lk(m_);
+    has_space_.wait(lk, [&] { return q_.size() < max_size_ || closed_; });
+    if (closed_) return false;
+    q_.push(s);
+    not_empty_.notify_all();
+    return true;
+  }
+  PySample* pop() {
+    std::unique_lock<std::mutex> lk(m_);
+    not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+    if (q_.empty()) throw std::runtime_error(error_.empty() ? "cslicer: queue closed" : error_);
+    PySample* s = q_.front();
+    q_.pop();
+    has_space_.notify_all();
+    return s;
+  }
+  void close(const std::string& err = "") {
+    std::lock_guard<std::mutex> lk(m_);
+    closed_ = true;
+    if (!err.empty()) error_ = err;
+    has_space_.notify_all();
+    not_empty_.notify_all();
+  }
+  void drain() {
+    std::lock_guard<std::mutex> lk(m_);
+    while (!q_.empty()) {
+      delete q_.front();
+      q_.pop();
+    }
+  }
+};
+
+void check(int rc, const char* what) {
+  if (rc < 0) throw std::runtime_error(std::string("cslicer: ") + what + ": " + csl_last_error());
+}
+
+// ---- CSlicer: pyfrontend.cpp:25-89
+class CSlicer {
+  std::string name_;
+  int queue_size_, workers_, epochs_, batch_;
+  int n_parts_, n_layers_;
+  long num_nodes_ = 0;
+  L0Dataset* dataset_ = nullptr;
+  csl_engine* eng_ = nullptr;
+  ReadyQueue ready_;
+  std::thread producer_;
+  std::atomic<bool> stop_{false};
+  std::atomic<long> handed_{0};
+  bool shuffle_;
+
+ public:
+  CSlicer(const std::string& name, int queue_size, int no_worker_threads, int number_of_epochs, int minibatch_size,
+          const std::string& data_root, const std::vector<int>& fanout, int n_parts, int device, unsigned seed,
+          bool shuffle)
+      : queue_size_(queue_size),
+        workers_(std::max(1, no_worker_threads)),
+        epochs_(number_of_epochs),
+        batch_(minibatch_size),
+        n_parts_(n_parts),
+        n_layers_((int)fanout.size()),
+        ready_(10),  // WorkerPool.cpp:23-24: capacity 10, the queue_size argument is ignored
+        shuffle_(shuffle) {
+    std::string root = data_root;
+    if (root.empty()) {
+      const char* env = std::getenv("CSLICER_DATA_ROOT");
+      root = env ? env : kDefaultRoot;
+    }
+    if (!root.empty() && root.back() != '/') root += "/";
+    name_ = root + name;
+    if (n_layers_ < 1 || n_layers_ > CSL_MAX_LAYERS) throw std::runtime_error("cslicer: 1..4 layers");
+    dataset_ = new L0Dataset(name_);
+    num_nodes_ = dataset_->num_nodes;
+    csl_config c;
+    std::memset(&c, 0, sizeof(c));
+    c.abi_version = CSL_ABI_VERSION;
+    c.device = device;
+    c.num_nodes = dataset_->num_nodes;
+    c.num_edges = dataset_->num_edges;
+    c.indptr = reinterpret_cast<const int64_t*>(dataset_->indptr.data());
+    c.indices = reinterpret_cast<const int64_t*>(dataset_->indices.data());
+    c.workload = nullptr;  // v % n_parts, pyfrontend.cpp:57
+    c.n_parts = n_parts;
+    c.n_layers = n_layers_;
+    for (int l = 0; l < n_layers_; l++) c.fanout[l] = fanout[l];
+    c.max_batch = minibatch_size;
+    c.n_streams = workers_;
+    c.n_slots = 2;
+    c.rng_seed = seed;
+    if (csl_create(&c, &eng_) < 0) {
+      delete dataset_;
+      dataset_ = nullptr;
+      throw std::runtime_error(std::string("cslicer: csl_create: ") + csl_last_error());
+    }
+    // the CSR now lives on the GPU; the host copy is not needed any more
+    std::vector<long>().swap(dataset_->indices);
+    std::vector<long>().swap(dataset_->indptr);
+    producer_ = std::thread(&CSlicer::run, this);  // pyfrontend.cpp:69
+  }
+
+  ~CSlicer() {
+    stop_ = true;
+    ready_.close();
+    if (producer_.joinable()) producer_.join();
+    ready_.drain();
+    if (eng_) csl_destroy(eng_);
+    delete dataset_;
+  }
+
+  long expected_number_of_samples() const {  // pyfrontend.cpp:80-83
+    const long per_epoch = (num_nodes_ - 1) / batch_ + 1;
+    return per_epoch * epochs_;
+  }
+
+  PySample* getSample() {  // pyfrontend.cpp:73-78 -> WorkerPool::pop_object
+    if (handed_ >= expected_number_of_samples())
+      throw std::runtime_error("cslicer: all samples already consumed (the reference would block forever)");
+    PySample* s = ready_.pop();
+    handed_++;
+    return s;
+  }
+
+ private:
+  PySample* fetch(int slot, int stream) {
+    csl_sample_meta m;
+    check(csl_get_meta(eng_, slot, stream, &m), "csl_get_meta");
+    PySample* s = empty_sample(n_layers_, n_parts_);
+    auto copy = [&](int l, int kind, int g, std::vector<long>& dst) {
+      const long n = (long)m.layer[l].off[kind][g + 1] - (long)m.layer[l].off[kind][g];
+      dst.resize(n);
+      if (n) {
+        const int64_t got = csl_copy_list(eng_, slot, stream, l, kind, g, reinterpret_cast<int64_t*>(dst.data()), n);
+        if (got != n) throw std::runtime_error(std::string("cslicer: csl_copy_list: ") + csl_last_error());
+      }
+    };
+    for (int l = 0; l < n_layers_; l++) {
+      for (int g = 0; g < n_parts_; g++) {
+        PyBipartite* b = (*s->layers[l])[g];
+        copy(l, CSL_IN_NODES, g, b->in_nodes);
+        copy(l, CSL_OUT_NODES, g, b->out_nodes);
+        copy(l, CSL_OWNED_OUT_NODES, g, b->owned_out_nodes);
+        copy(l, CSL_SELF_IDS_IN, g, b->self_ids_in);
+        copy(l, CSL_SELF_IDS_OUT, g, b->self_ids_out);
+        copy(l, CSL_TO_IDS, g, b->to_ids[g]);      // own index only, slicer.cpp:41
+        copy(l, CSL_FROM_IDS, g, b->from_ids[g]);  // slicer.cpp:42
+        b->indptr.assign(b->out_nodes.size(), 1);  // bipartite.h:55-66: one `1` per push, CSR never built
+        if (l == 0) s->in_nodes += (long)b->in_nodes.size();
+        if (g == 2) s->out_nodes += (long)b->out_nodes.size();
+      }
+    }
+    return s;
+  }
+
+  // WorkerPool::run (WorkerPool.cpp:37-60)
+  void run() {
+    try {
+      std::vector<long> nodes(num_nodes_);
+      for (long i = 0; i < num_nodes_; i++) nodes[i] = i;  // WorkerPool.cpp:12-16
+      const long per_epoch = (num_nodes_ - 1) / batch_ + 1;
+      const long rounds = (per_epoch + workers_ - 1) / workers_;
+      for (int epoch = 0; epoch < epochs_ && !stop_; epoch++) {
+        if (shuffle_) std::random_shuffle(nodes.begin(), nodes.end());  // WorkerPool.cpp:40
+        check(csl_set_nodes(eng_, reinterpret_cast<const int64_t*>(nodes.data()), num_nodes_), "csl_set_nodes");
+        int inflight_slot = -1, inflight_n = 0;
+        for (long r = 0; r <= rounds && !stop_; r++) {
+          int slot = (int)(r & 1), nb = 0;
+          if (r < rounds) {
+            nb = (int)std::min<long>(workers_, per_epoch - r * workers_);
+            check(csl_submit_round(eng_, r * workers_, batch_, nb, slot), "csl_submit_round");
+          }
+          // hand out the previous round while the GPU works on this one
+          for (int s = 0; s < inflight_n && !stop_; s++) {
+            PySample* smp = fetch(inflight_slot, s);
+            if (!ready_.push(smp)) {
+              delete smp;
+              return;
+            }
+          }
+          inflight_slot = slot;
+          inflight_n = nb;
+        }
+      }
+    } catch (const std::exception& ex) {
+      ready_.close(ex.what());
+    }
+  }
+};
+
+py::list testlist(py::list l) {  // pyfrontend.cpp:94-109
+  std::vector<int> v = {1, 2, 3, 4};
+  py::list out = py::cast(v);
+  (void)l;  // the reference appends 10 to the caster's temporary copy, invisible to the caller
+  return out;
+}
+
+PySample* testpysample() { return empty_sample(3, 4); }  // pyfrontend.cpp:111-114
+
+}  // namespace
+
+PYBIND11_MODULE(cslicer, m) {
+  m.doc() = "MI355X-native cslicer: drop-in for the reference pybind11 module";
+  m.def("test_list", &testlist, "List testing ");
+  m.def("test_pyfront", &testpysample, "List testing ", py::return_value_policy::take_ownership);
+  py::class_<PySample>(m, "sample").def_readwrite("layers", &PySample::layers);
+  py::class_<PyBipartite>(m, "bipatite")
+      .def_readwrite("in_nodes", &PyBipartite::in_nodes)
+      .def_readwrite("indptr", &PyBipartite::indptr)
+      .def_readwrite("out_nodes", &PyBipartite::out_nodes)
+      .def_readwrite("owned_out_nodes", &PyBipartite::owned_out_nodes)
+      .def_readwrite("indices", &PyBipartite::indices)
+      .def_readwrite("from_ids", &PyBipartite::from_ids)
+      .def_readwrite("to_ids", &PyBipartite::to_ids)
+      .def_readwrite("self_ids_in", &PyBipartite::self_ids_in)
+      .def_readwrite("self_ids_out", &PyBipartite::self_ids_out)
+      .def_readwrite("gpu_id", &PyBipartite::gpu_id);
+  py::class_<CSlicer>(m, "cslicer")
+      .def(py::init<const std::string&, int, int, int, int, const std::string&, const std::vector<int>&, int, int,
+                    unsigned, bool>(),
+           py::arg("name"), py::arg("queue_size"), py::arg("no_worker_threads"), py::arg("number_of_epochs"),
+           py::arg("minibatch_size"), py::arg("data_root") = std::string(),
+           py::arg("fanout") = std::vector<int>{10, 10, 10}, py::arg("n_parts") = 4, py::arg("device") = 0,
+           py::arg("seed") = 5489u, py::arg("shuffle") = true)
+      .def("getSample", &CSlicer::getSample, py::return_value_policy::take_ownership,
+           py::call_guard<py::gil_scoped_release>())
+      .def("getNoSamples", &CSlicer::expected_number_of_samples);
+}

@@ -16,3 +16,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def load_native_module():
+    """The C++/pybind11 `cslicer` module (occ-gnn_amd/pybind/), loaded without
+    shadowing the Python package of the same name."""
+    import glob
+    import importlib.util
+    hits = glob.glob(os.path.join(ROOT, "occ-gnn_amd", "pybind", "cslicer*.so"))
+    if not hits:
+        raise ImportError("native cslicer module not built (make -C occ-gnn_amd/csrc)")
+    spec = importlib.util.spec_from_file_location("cslicer", hits[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

@@ -94,3 +94,33 @@ def test_l0_roundtrip_and_meta(tmp_path):
     np.testing.assert_array_equal(b, indices)
     assert m["num_nodes"] == 500
     assert open(os.path.join(d, "meta.txt")).read().endswith("\n")
+
+
+def test_native_pybind_module_surface():
+    # the C++ host side: same module name and members as the reference's pybind11 module
+    from conftest import load_native_module
+    m = load_native_module()
+    assert sorted(n for n in dir(m) if not n.startswith("_")) == ["bipatite", "cslicer", "sample",
+                                                                  "test_list", "test_pyfront"]
+    s = m.test_pyfront()
+    assert len(s.layers) == 3 and all(len(r) == 4 for r in s.layers)
+    b = s.layers[2][3]
+    assert b.gpu_id == 3 and b.in_nodes == [] and b.from_ids == [[], [], [], []]
+    b.in_nodes = [4, 5]          # def_readwrite: assignment works, reads copy
+    got = b.in_nodes
+    got.append(6)
+    assert b.in_nodes == [4, 5]
+    arg = [1, 2, 3]
+    assert m.test_list(arg) == [1, 2, 3, 4] and arg == [1, 2, 3]
+    import inspect
+    doc = m.cslicer.__init__.__doc__
+    for a in ("name", "queue_size", "no_worker_threads", "number_of_epochs", "minibatch_size"):
+        assert a in doc
+
+
+def test_native_module_missing_dataset_raises(tmp_path):
+    from conftest import load_native_module
+    m = load_native_module()
+    import pytest
+    with pytest.raises(RuntimeError):
+        m.cslicer("nope", 16, 2, 1, 64, data_root=str(tmp_path))

@@ -284,3 +284,57 @@ def test_frontend_module_end_to_end(abi, orc, tmp_path, monkeypatch):
                         assert getattr(bp, name) == wb[name].tolist(), (ep, b, l, g, name)
                     assert bp.from_ids == [x.tolist() for x in wb["from_ids"]]
                     assert bp.to_ids == [x.tolist() for x in wb["to_ids"]]
+
+
+def test_native_pybind_module_end_to_end(orc, tmp_path):
+    """C++ host side (occ-gnn_amd/csrc/pymodule.cpp): producer thread, epoch shuffle via
+    std::random_shuffle, rounds on the GPU, PySample objects -- against one oracle per worker."""
+    import ctypes
+    from conftest import load_native_module
+    from cslicer import l0
+    from cslicer.frontend import epoch_shuffle
+    m = load_native_module()
+    n = 5000
+    indptr, indices = l0.synth_graph(n, 18.0, seed=33)
+    l0.write_l0(str(tmp_path / "g5k"), indptr, indices)
+    libc = ctypes.CDLL(None)
+    libc.srand(1)
+    S, B, epochs = 4, 512, 2
+    csl = m.cslicer("g5k", 16, S, epochs, B, data_root=str(tmp_path))
+    ns = csl.getNoSamples()
+    samples = [csl.getSample() for _ in range(ns)]
+    with pytest.raises(RuntimeError):
+        csl.getSample()
+    del csl
+    libc.srand(1)
+    nodes = np.arange(n, dtype=np.int64)
+    oracles = [orc.Oracle(indptr, indices) for _ in range(S)]
+    k = 0
+    for ep in range(epochs):
+        epoch_shuffle(nodes)
+        for b in range((n - 1) // B + 1):
+            want = oracles[b % S].sample(nodes[b * B:(b + 1) * B])
+            s = samples[k]
+            k += 1
+            for l in range(3):
+                for g in range(4):
+                    bp, wb = s.layers[l][g], want["layers"][l][g]
+                    assert bp.gpu_id == g
+                    for name in ("in_nodes", "indptr", "out_nodes", "owned_out_nodes", "indices",
+                                 "self_ids_in", "self_ids_out"):
+                        assert getattr(bp, name) == wb[name].tolist(), (ep, b, l, g, name)
+                    assert bp.from_ids == [x.tolist() for x in wb["from_ids"]]
+                    assert bp.to_ids == [x.tolist() for x in wb["to_ids"]]
+    assert k == ns
+
+
+def test_native_module_destructor_does_not_deadlock(tmp_path):
+    # the reference's ~CSlicer joins a producer blocked on a full queue (pyfrontend.cpp:85-88)
+    from conftest import load_native_module
+    from cslicer import l0
+    m = load_native_module()
+    indptr, indices = l0.synth_graph(4000, 10.0, seed=2)
+    l0.write_l0(str(tmp_path / "g"), indptr, indices)
+    csl = m.cslicer("g", 16, 2, 3, 64, data_root=str(tmp_path))
+    csl.getSample()
+    del csl   # dozens of samples never consumed
