@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     return ap.parse_args()
 
 
@@ -118,12 +119,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: the cslicer engine has no CPU path")
+    device = local_rank % ndev
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     if args.gpus != world and rank == 0 and world > 1:
         sys.stderr.write("[bench] --gpus %d but WORLD_SIZE %d; using WORLD_SIZE\n" % (args.gpus, world))
 
@@ -138,7 +147,7 @@ def main():
     S, B, P = args.streams, args.batch, args.parts
     perm = np.random.default_rng(1).permutation(N).astype(np.int64)
     eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2,
-                      device=local_rank)
+                      device=device)
     eng.set_nodes(perm)
     from cslicer import shard
     n_rounds, n_batches = shard.rounds_per_epoch(N, B, S)  # full rounds only: every step does S minibatches
@@ -163,7 +172,7 @@ def main():
     for w in range(args.warmup):
         run_round(w)
     eng.sync()
-    dt = shard.max_over_ranks(timed(args.steps, args.warmup), dist, "cuda")
+    dt = shard.max_over_ranks(timed(args.steps, args.warmup), dist, red_dev)
 
     # ---- units processed: read the last two rounds' metas (both slots)
     def slot_stats(slot):
@@ -187,7 +196,7 @@ def main():
 
     stats = slot_stats((args.warmup + args.steps - 1) & 1)
     edges_per_round = sum(d["E"] for d in stats)
-    total_edges = shard.sum_over_ranks(edges_per_round * args.steps, dist, "cuda")
+    total_edges = shard.sum_over_ranks(edges_per_round * args.steps, dist, red_dev)
     iters = args.steps * S * world
     value = total_edges / dt
 

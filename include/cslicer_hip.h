@@ -148,6 +148,14 @@ int csl_get_meta(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* o
 int64_t csl_copy_list(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind,
                       int32_t part, int64_t* dst, int64_t cap);
 
+/* PySample(Sample*) in one call: every list of one sample copied to a pinned host
+ * buffer the engine owns (valid until the next csl_fetch_sample on this engine).
+ * seg[l][k] = element offset in *host_ptr of kind k of layer l (its parts back to
+ * back, split with meta->layer[l].off[k][..]).  One batch of async copies and one
+ * wait instead of layers x parts x kinds blocking copies. */
+int csl_fetch_sample(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta,
+                     const int64_t** host_ptr, int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS]);
+
 /* zero-copy surface: device pointer of the kind's int64 array (all parts back
  * to back, offsets in csl_layer_meta.off) */
 int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind,

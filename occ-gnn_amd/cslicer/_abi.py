@@ -29,6 +29,7 @@ SYMBOLS = [
     "csl_submit_round", "csl_submit_seeds", "csl_sync", "csl_get_meta", "csl_copy_list",
     "csl_list_device_ptr", "csl_frontier_device_ptr", "csl_copy_frontier", "csl_hip_stream",
     "csl_timing_enable", "csl_timing_read", "csl_kernel_name", "csl_rng_peek", "csl_device_bytes",
+    "csl_fetch_sample",
 ]
 
 
@@ -107,6 +108,8 @@ def load():
     L.csl_copy_list.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, p64, C.c_int64]
     L.csl_copy_list.restype = C.c_int64
     L.csl_list_device_ptr.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.csl_fetch_sample.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(SampleMeta), C.POINTER(p64),
+                                   C.POINTER((C.c_int64 * NUM_LISTS) * MAX_LAYERS)]
     L.csl_frontier_device_ptr.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.csl_copy_frontier.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, p64, C.c_int64]
     L.csl_copy_frontier.restype = C.c_int64
@@ -243,6 +246,22 @@ class Engine:
         p = C.c_void_p()
         _check(load().csl_hip_stream(self._h, C.byref(p)))
         return p.value
+
+    def fetch_sample(self, stream=0, slot=0):
+        """All lists of one sample through csl_fetch_sample: {(layer, kind): [parts...]} of numpy copies."""
+        m = SampleMeta()
+        ptr = C.POINTER(C.c_int64)()
+        seg = ((C.c_int64 * NUM_LISTS) * MAX_LAYERS)()
+        _check(load().csl_fetch_sample(self._h, slot, stream, C.byref(m), C.byref(ptr), C.byref(seg)))
+        out = {}
+        for l in range(self.n_layers):
+            for k in range(NUM_LISTS):
+                tot = int(m.layer[l].off[k][self.n_parts])
+                flat = (np.ctypeslib.as_array(ptr, shape=(int(seg[l][k]) + tot,))[int(seg[l][k]):].copy()
+                        if tot else np.zeros(0, dtype=np.int64))
+                out[(l, k)] = [flat[int(m.layer[l].off[k][g]):int(m.layer[l].off[k][g + 1])]
+                               for g in range(self.n_parts)]
+        return m, out
 
     def sample_dict(self, stream=0, slot=0):
         """One sample as a dict of numpy lists (the shape the parity tests compare)."""

@@ -1081,6 +1081,10 @@ struct csl_engine {
   // batch descriptors
   BatchDesc* desc_dev = nullptr;   // [slots][S]
   BatchDesc* desc_host = nullptr;  // pinned, [slots][S]
+  // pinned staging for csl_fetch_sample
+  long long* fetch_host = nullptr;
+  size_t fetch_cap = 0;
+  hipStream_t copy_stream = nullptr;
   // host mirror of meta for fetches
   std::vector<csl_sample_meta> meta_host;
   std::vector<char> meta_valid;  // per slot
@@ -1376,6 +1380,8 @@ void csl_destroy(csl_engine* e) {
   for (int l = 0; l < CSL_MAX_LAYERS; l++)
     if (e->arena[l]) hipFree(e->arena[l]);
   if (e->desc_host) hipHostFree(e->desc_host);
+  if (e->fetch_host) hipHostFree(e->fetch_host);
+  if (e->copy_stream) hipStreamDestroy(e->copy_stream);
   if (e->rng_event) hipEventDestroy(e->rng_event);
   for (auto ev : e->slot_event) hipEventDestroy(ev);
   if (e->stream) hipStreamDestroy(e->stream);
@@ -1701,6 +1707,40 @@ int64_t csl_copy_list(csl_engine* e, int32_t slot, int32_t stream, int32_t layer
     if (er != hipSuccess) return fail(CSL_E_HIP, "hipMemcpy failed: %s", hipGetErrorString(er));
   }
   return n;
+}
+
+int csl_fetch_sample(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta, const int64_t** host_ptr,
+                     int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS]) {
+  if (!e || !meta || !host_ptr || !seg) return fail(CSL_E_INVALID, "null argument");
+  if (slot < 0 || slot >= e->slots || stream < 0 || stream >= e->S) return fail(CSL_E_INVALID, "slot/stream out of range");
+  HIPCHECK(hipSetDevice(e->cfg.device));
+  int r = load_meta(e, slot);
+  if (r) return r;
+  const csl_sample_meta& sm = e->meta_host[(size_t)slot * e->S + stream];
+  *meta = sm;
+  if (sm.error) return fail(CSL_E_DEVICE, "device flagged error bits 0x%x in slot %d stream %d", sm.error, slot, stream);
+  if (!e->fetch_host) {
+    size_t cap = 0;
+    for (int l = 0; l < e->L; l++) cap += e->arena_stride[l];
+    HIPCHECK(hipHostMalloc((void**)&e->fetch_host, cap * sizeof(long long), hipHostMallocDefault));
+    e->fetch_cap = cap;
+    HIPCHECK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  }
+  size_t o = 0;
+  for (int l = 0; l < e->L; l++) {
+    const long long* base = e->arena[l] + ((size_t)slot * e->S + stream) * e->arena_stride[l];
+    for (int k = 0; k < CSL_NUM_LISTS; k++) {
+      const size_t n = sm.layer[l].off[k][e->P];
+      seg[l][k] = (int64_t)o;
+      if (n)
+        HIPCHECK(hipMemcpyAsync(e->fetch_host + o, base + e->list_base[l][k], n * sizeof(long long),
+                                hipMemcpyDeviceToHost, e->copy_stream));
+      o += n;
+    }
+  }
+  HIPCHECK(hipStreamSynchronize(e->copy_stream));
+  *host_ptr = (const int64_t*)e->fetch_host;
+  return 0;
 }
 
 int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind, const int64_t** out) {

@@ -251,26 +251,25 @@ class CSlicer {
  private:
   PySample* fetch(int slot, int stream) {
     csl_sample_meta m;
-    check(csl_get_meta(eng_, slot, stream, &m), "csl_get_meta");
+    const int64_t* host = nullptr;
+    int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS];
+    check(csl_fetch_sample(eng_, slot, stream, &m, &host, seg), "csl_fetch_sample");
     PySample* s = empty_sample(n_layers_, n_parts_);
-    auto copy = [&](int l, int kind, int g, std::vector<long>& dst) {
-      const long n = (long)m.layer[l].off[kind][g + 1] - (long)m.layer[l].off[kind][g];
-      dst.resize(n);
-      if (n) {
-        const int64_t got = csl_copy_list(eng_, slot, stream, l, kind, g, reinterpret_cast<int64_t*>(dst.data()), n);
-        if (got != n) throw std::runtime_error(std::string("cslicer: csl_copy_list: ") + csl_last_error());
-      }
+    auto take = [&](int l, int kind, int g, std::vector<long>& dst) {
+      const long lo = (long)m.layer[l].off[kind][g], hi = (long)m.layer[l].off[kind][g + 1];
+      const long* src = reinterpret_cast<const long*>(host) + seg[l][kind] + lo;
+      dst.assign(src, src + (hi - lo));
     };
     for (int l = 0; l < n_layers_; l++) {
       for (int g = 0; g < n_parts_; g++) {
         PyBipartite* b = (*s->layers[l])[g];
-        copy(l, CSL_IN_NODES, g, b->in_nodes);
-        copy(l, CSL_OUT_NODES, g, b->out_nodes);
-        copy(l, CSL_OWNED_OUT_NODES, g, b->owned_out_nodes);
-        copy(l, CSL_SELF_IDS_IN, g, b->self_ids_in);
-        copy(l, CSL_SELF_IDS_OUT, g, b->self_ids_out);
-        copy(l, CSL_TO_IDS, g, b->to_ids[g]);      // own index only, slicer.cpp:41
-        copy(l, CSL_FROM_IDS, g, b->from_ids[g]);  // slicer.cpp:42
+        take(l, CSL_IN_NODES, g, b->in_nodes);
+        take(l, CSL_OUT_NODES, g, b->out_nodes);
+        take(l, CSL_OWNED_OUT_NODES, g, b->owned_out_nodes);
+        take(l, CSL_SELF_IDS_IN, g, b->self_ids_in);
+        take(l, CSL_SELF_IDS_OUT, g, b->self_ids_out);
+        take(l, CSL_TO_IDS, g, b->to_ids[g]);      // own index only, slicer.cpp:41
+        take(l, CSL_FROM_IDS, g, b->from_ids[g]);  // slicer.cpp:42
         b->indptr.assign(b->out_nodes.size(), 1);  // bipartite.h:55-66: one `1` per push, CSR never built
         if (l == 0) s->in_nodes += (long)b->in_nodes.size();
         if (g == 2) s->out_nodes += (long)b->out_nodes.size();

@@ -338,3 +338,18 @@ def test_native_module_destructor_does_not_deadlock(tmp_path):
     csl = m.cslicer("g", 16, 2, 3, 64, data_root=str(tmp_path))
     csl.getSample()
     del csl   # dozens of samples never consumed
+
+
+def test_fetch_sample_matches_per_list_copies(abi):
+    indptr, indices = _rand_graph(3000, 20.0, seed=9)
+    perm = np.random.default_rng(3).permutation(3000)
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 10, 10), max_batch=128, n_streams=2)
+    e.set_nodes(perm)
+    e.submit_round(0, 128, 2)
+    for s in range(2):
+        m, lists = e.fetch_sample(s)
+        for l in range(3):
+            for k in range(abi.NUM_LISTS):
+                for g in range(4):
+                    np.testing.assert_array_equal(lists[(l, k)][g], e.copy_list(l, k, g, s))
+    e.close()
