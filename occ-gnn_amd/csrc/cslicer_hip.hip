@@ -1,7 +1,7 @@
 // cslicer_hip.hip -- MI355X (gfx950) cslicer engine: kernels + C ABI.
 //
 // What the reference does sequentially per minibatch (cslicer/slicer.cpp:25-64,
-// bipartite.cpp:3-17, util/duplicate.cpp:14-39) is restated here as seven
+// bipartite.cpp:3-17, util/duplicate.cpp:14-39) is restated here as ten
 // data-parallel passes per layer over S minibatches ("streams") at once.
 // Order-dependent semantics (first-occurrence dedup, consecutive-dedup lists,
 // the single mt19937 stream) are recovered from each element's position in the
