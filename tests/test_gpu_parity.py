@@ -353,3 +353,52 @@ def test_fetch_sample_matches_per_list_copies(abi):
                 for g in range(4):
                     np.testing.assert_array_equal(lists[(l, k)][g], e.copy_list(l, k, g, s))
     e.close()
+
+
+def test_baseline_config0_arxiv_like_two_layers(abi, orc):
+    """BASELINE configs[0] shape: arxiv-like (N=169,343, mean degree 6.9), 2-layer fanout 10/10,
+    batch 1024 -- the reference's CPU-runnable case, here GPU vs oracle, 4 parts."""
+    from cslicer import l0
+    n, d, _, _ = l0.PRESETS["arxiv-like"]
+    indptr, indices = l0.synth_graph(n, d, seed=0)
+    perm = np.random.default_rng(1).permutation(n)
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 10), max_batch=1024, n_streams=4)
+    e.set_nodes(perm)
+    oracles = [orc.Oracle(indptr, indices, n_parts=4, fanouts=(10, 10)) for _ in range(4)]
+    for r in range(2):
+        e.submit_round(r * 4, 1024, 4)
+        for s in range(4):
+            want = oracles[s].sample(perm[(r * 4 + s) * 1024:(r * 4 + s + 1) * 1024])
+            assert_same_sample(e.sample_dict(s), want, what="arxiv-like round %d stream %d" % (r, s))
+    e.close()
+
+
+def test_baseline_config2_batch_4096(abi, orc):
+    """BASELINE configs[2] shape: fanout 15/10/5, batch 4096, 4 parts (products-like degrees on a
+    400k-node graph so the oracle finishes in seconds)."""
+    indptr, indices = _rand_graph(400_000, 50.5, seed=0)
+    perm = np.random.default_rng(1).permutation(400_000)
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(15, 10, 5), max_batch=4096, n_streams=2)
+    e.set_nodes(perm)
+    e.submit_round(0, 4096, 2)
+    for s in range(2):
+        want = orc.Oracle(indptr, indices, n_parts=4, fanouts=(15, 10, 5)).sample(perm[s * 4096:(s + 1) * 4096])
+        assert_same_sample(e.sample_dict(s), want, what="batch-4096 stream %d" % s)
+    e.close()
+
+
+def test_eight_parts_workload_table_large_fanout(abi, orc):
+    # 8 parts from a partition table (the METIS-map use case, partition_map_opt.bin) and a
+    # fanout above 16 (candidate stride 26)
+    n = 30_000
+    indptr, indices = _rand_graph(n, 60.0, seed=8)
+    rng = np.random.default_rng(5)
+    wl = rng.integers(0, 8, size=n).astype(np.int32)
+    perm = rng.permutation(n)
+    e = abi.Engine(indptr, indices, n_parts=8, fanouts=(25, 3), max_batch=300, n_streams=2, workload=wl)
+    e.set_nodes(perm)
+    e.submit_round(0, 300, 2)
+    for s in range(2):
+        want = orc.Oracle(indptr, indices, n_parts=8, fanouts=(25, 3), workload=wl).sample(perm[s * 300:(s + 1) * 300])
+        assert_same_sample(e.sample_dict(s), want, what="8 parts stream %d" % s)
+    e.close()
