@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--nodes", type=int, default=2_449_029)
     ap.add_argument("--mean-deg", type=float, default=50.5)
     ap.add_argument("--graph-seed", type=int, default=0)
+    ap.add_argument("--unsorted-rows", action="store_true", help="skip the per-row sort of the generator (huge graphs)")
+    ap.add_argument("--no-graph-cache", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -53,13 +55,18 @@ def parse():
 def get_graph(args, rank, barrier):
     """Synthetic L0-shaped graph; rank 0 generates and caches, others load."""
     from cslicer import l0
-    key = "g_n%d_d%g_s%d" % (args.nodes, args.mean_deg, args.graph_seed)
+    if args.no_graph_cache:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("--no-graph-cache is single-rank only")
+        return l0.synth_graph(args.nodes, args.mean_deg, seed=args.graph_seed, sort_rows=not args.unsorted_rows)
+    key = "g_n%d_d%g_s%d%s" % (args.nodes, args.mean_deg, args.graph_seed, "_u" if args.unsorted_rows else "")
     cache = os.path.join(os.environ.get("CSLICER_BENCH_CACHE", "/tmp/cslicer_bench_cache"), key)
     ok = os.path.join(cache, "ok")
     if rank == 0 and not os.path.exists(ok):
         os.makedirs(cache, exist_ok=True)
         t0 = time.time()
-        indptr, indices = l0.synth_graph(args.nodes, args.mean_deg, seed=args.graph_seed)
+        indptr, indices = l0.synth_graph(args.nodes, args.mean_deg, seed=args.graph_seed,
+                                         sort_rows=not args.unsorted_rows)
         np.save(os.path.join(cache, "indptr.npy"), indptr)
         np.save(os.path.join(cache, "indices.npy"), indices)
         open(ok, "w").write("ok\n")

@@ -34,7 +34,7 @@ extern "C" {
 
 #define CSL_MAX_PARTS 8
 #define CSL_MAX_LAYERS 4
-#define CSL_ABI_VERSION 1
+#define CSL_ABI_VERSION 2
 
 enum {
   CSL_OK = 0,
@@ -63,10 +63,31 @@ enum {
   CSL_SELF_IDS_OUT = 4,     /* local index into out_nodes or -1 */
   CSL_TO_IDS = 5,           /* to_ids[gpu_id]  (only the own index is ever filled, slicer.cpp:41) */
   CSL_FROM_IDS = 6,         /* from_ids[gpu_id] (slicer.cpp:42) */
-  CSL_NUM_LISTS = 7
-  /* `indptr` is len(out_nodes) ones and `indices` is empty in the reference's
-   * exported object (bipartite.h:55-66 never builds the CSR); the host binding
-   * synthesises both, they are not stored on the device. */
+  /* CSL_MODE_STRICT: `indptr` is len(out_nodes) ones and `indices` is empty in the
+   * reference's exported object (bipartite.h:55-66 never builds the CSR); the host
+   * binding synthesises both, the three kinds below stay empty on the device.
+   * CSL_MODE_GRAPH fills them (see csl_config.mode). */
+  CSL_INDPTR = 7,           /* graph mode: CSR row pointers over out_nodes, len(out_nodes)+1 per part */
+  CSL_INDICES = 8,          /* graph mode: local index into in_nodes of every edge's source */
+  CSL_OWNED_DEGREE = 9,     /* graph mode: edges of each owned out node over ALL parts (mean divisor) */
+  CSL_NUM_LISTS = 10
+};
+
+/* csl_config.mode */
+enum {
+  /* bit-exact reproduction of the object the reference exports (default) */
+  CSL_MODE_STRICT = 0,
+  /* the object the reference meant to export: same sampling, same frontiers, but
+   *  - a real CSR per slice (indptr/indices; sampled self loops dropped),
+   *  - every frontier node owned by g is an out node AND an in node of slice g
+   *    (its self entry counts as a source), so self_ids_* never hold -1,
+   *  - from_ids / to_ids per ordered pair of parts: slice g's from_ids segment is
+   *    split by receiver p (csl_layer_meta.pair_off[0][g][p]), slice p's to_ids
+   *    segment by sender g (pair_off[1][p][g]); list (g -> p) has the same length
+   *    and node order on both sides,
+   *  - owned_degree.
+   * Specification: oracle/cslicer_oracle.c::orc_sample_graph. */
+  CSL_MODE_GRAPH = 1
 };
 
 typedef struct {
@@ -89,6 +110,8 @@ typedef struct {
   uint32_t rng_ring_log2;    /* log2 of the device mt19937 window in 32-bit words (0 => 26) */
   /* optional frontier capacity per layer input (0 => worst case batch*prod(fanout+1)) */
   int64_t frontier_cap[CSL_MAX_LAYERS + 1];
+  int32_t mode;              /* CSL_MODE_STRICT (0) or CSL_MODE_GRAPH */
+  int32_t reserved;
 } csl_config;
 
 typedef struct {
@@ -98,6 +121,9 @@ typedef struct {
   uint32_t sampled_edges;    /* neighbour_sample entries excluding the leading self entry */
   /* list g of kind k occupies [off[k][g], off[k][g+1]) of the kind's array */
   uint32_t off[CSL_NUM_LISTS][CSL_MAX_PARTS + 1];
+  /* graph mode: pair_off[0][g][p] = start of (g -> p) inside slice g's from_ids
+   * segment, pair_off[1][p][g] = start of (g -> p) inside slice p's to_ids segment */
+  uint32_t pair_off[2][CSL_MAX_PARTS][CSL_MAX_PARTS + 1];
 } csl_layer_meta;
 
 typedef struct {
@@ -172,7 +198,7 @@ int csl_hip_stream(csl_engine* e, void** out);
 
 /* time the dominant kernels of the last rounds with HIP events on the
  * engine's own stream: enable, run rounds, read back per-kernel totals */
-#define CSL_NUM_KERNELS 12
+#define CSL_NUM_KERNELS 13
 int csl_timing_enable(csl_engine* e, int32_t on);
 int csl_timing_read(csl_engine* e, double* ms_total /*[CSL_NUM_KERNELS]*/,
                     int64_t* launches /*[CSL_NUM_KERNELS]*/);

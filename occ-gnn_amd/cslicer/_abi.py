@@ -13,10 +13,12 @@ LIB_PATH = os.path.join(os.path.dirname(HERE), "lib", "libcslicer_hip.so")
 
 MAX_PARTS = 8
 MAX_LAYERS = 4
-ABI_VERSION = 1
-NUM_LISTS = 7
-NUM_KERNELS = 12
-(IN_NODES, OUT_NODES, OWNED_OUT_NODES, SELF_IDS_IN, SELF_IDS_OUT, TO_IDS, FROM_IDS) = range(7)
+ABI_VERSION = 2
+NUM_LISTS = 10
+NUM_KERNELS = 13
+(IN_NODES, OUT_NODES, OWNED_OUT_NODES, SELF_IDS_IN, SELF_IDS_OUT, TO_IDS, FROM_IDS,
+ INDPTR, INDICES, OWNED_DEGREE) = range(10)
+MODE_STRICT, MODE_GRAPH = 0, 1
 LIST_KINDS = {
     "in_nodes": IN_NODES, "out_nodes": OUT_NODES, "owned_out_nodes": OWNED_OUT_NODES,
     "self_ids_in": SELF_IDS_IN, "self_ids_out": SELF_IDS_OUT, "to_ids": TO_IDS, "from_ids": FROM_IDS,
@@ -51,6 +53,8 @@ class Config(C.Structure):
         ("rng_seed", C.c_uint32),
         ("rng_ring_log2", C.c_uint32),
         ("frontier_cap", C.c_int64 * (MAX_LAYERS + 1)),
+        ("mode", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -61,6 +65,7 @@ class LayerMeta(C.Structure):
         ("draws", C.c_uint32),
         ("sampled_edges", C.c_uint32),
         ("off", (C.c_uint32 * (MAX_PARTS + 1)) * NUM_LISTS),
+        ("pair_off", ((C.c_uint32 * (MAX_PARTS + 1)) * MAX_PARTS) * 2),
     ]
 
 
@@ -138,7 +143,7 @@ class Engine:
 
     def __init__(self, indptr, indices, n_parts=4, fanouts=(10, 10, 10), max_batch=1024,
                  n_streams=1, n_slots=1, workload=None, device=0, rng_seed=5489,
-                 rng_ring_log2=0, frontier_cap=None):
+                 rng_ring_log2=0, frontier_cap=None, mode=MODE_STRICT):
         L = load()
         self._h = None
         self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
@@ -167,6 +172,8 @@ class Engine:
         cfg.n_slots = self.n_slots
         cfg.rng_seed = rng_seed
         cfg.rng_ring_log2 = rng_ring_log2
+        cfg.mode = mode
+        self.mode = mode
         if frontier_cap is not None:
             for l, c in enumerate(frontier_cap):
                 cfg.frontier_cap[l] = int(c)
@@ -293,6 +300,35 @@ class Engine:
             out["frontier"].append(self.copy_frontier(l, stream, slot, m))
         out["draws_total"] = int(m.rng_end)
         out["rng_begin"] = int(m.rng_begin)
+        return out
+
+    def graph_dict(self, stream=0, slot=0):
+        """One sample of a CSL_MODE_GRAPH engine: real slice CSR + per-peer boundary lists."""
+        if self.mode != MODE_GRAPH:
+            raise ValueError("engine was not created with mode=MODE_GRAPH")
+        m, lists = self.fetch_sample(stream, slot)
+        out = {"layers": [], "frontier": [], "sampled_edges": 0}
+        P = self.n_parts
+        for l in range(self.n_layers):
+            parts = []
+            lm = m.layer[l]
+            for g in range(P):
+                bp = {
+                    "in_nodes": lists[(l, IN_NODES)][g], "out_nodes": lists[(l, OUT_NODES)][g],
+                    "indptr": lists[(l, INDPTR)][g], "indices": lists[(l, INDICES)][g],
+                    "owned_out_nodes": lists[(l, OWNED_OUT_NODES)][g],
+                    "self_ids_in": lists[(l, SELF_IDS_IN)][g], "self_ids_out": lists[(l, SELF_IDS_OUT)][g],
+                    "owned_degree": lists[(l, OWNED_DEGREE)][g], "gpu_id": g,
+                }
+                fr, to = lists[(l, FROM_IDS)][g], lists[(l, TO_IDS)][g]
+                bp["from_ids"] = [fr[int(lm.pair_off[0][g][p]):int(lm.pair_off[0][g][p + 1])] for p in range(P)]
+                bp["to_ids"] = [to[int(lm.pair_off[1][g][p]):int(lm.pair_off[1][g][p + 1])] for p in range(P)]
+                parts.append(bp)
+            out["layers"].append(parts)
+            out["sampled_edges"] += int(lm.sampled_edges)
+        for l in range(self.n_layers + 1):
+            out["frontier"].append(self.copy_frontier(l, stream, slot, m))
+        out["draws_total"] = int(m.rng_end)
         return out
 
     # -- measurement / test hooks

@@ -65,14 +65,18 @@ __host__ __device__ constexpr int K_OWNED(int P, int g) { return 3 + 2 * P + g; 
 __host__ __device__ constexpr int K_SELF(int P, int g) { return 3 + 3 * P + g; }
 __host__ __device__ constexpr int K_TO(int P, int g) { return 3 + 4 * P + g; }
 __host__ __device__ constexpr int K_FROM(int P, int g) { return 3 + 5 * P + g; }
-__host__ __device__ constexpr int NKINDS(int P) { return 3 + 6 * P; }
-constexpr int MAXK = 3 + 6 * CSL_MAX_PARTS;
+// graph mode only: edges per source part (CSR sizes) and boundary pairs (sender g, receiver p)
+__host__ __device__ constexpr int K_ECNT(int P, int g) { return 3 + 6 * P + g; }
+__host__ __device__ constexpr int K_PAIR(int P, int g, int p) { return 3 + 7 * P + g * P + p; }
+__host__ __device__ constexpr int NKINDS(int P, bool graph) { return graph ? 3 + 7 * P + P * P : 3 + 6 * P; }
+constexpr int MAXK = 3 + 7 * CSL_MAX_PARTS + CSL_MAX_PARTS * CSL_MAX_PARTS;
 
 enum { KN_SEEDS = 0, KN_DEGREE, KN_SCAN_A, KN_SAMPLE, KN_SCAN_Q, KN_SCATTER, KN_BUCKET, KN_COUNT, KN_SCAN_B,
-       KN_EMIT, KN_SELFIN, KN_MT };
+       KN_EMIT, KN_SELFIN, KN_MT, KN_EDGES };
 const char* const kKernelNames[CSL_NUM_KERNELS] = {"k_seeds",   "k_degree", "k_scan_need", "k_sample",
                                                    "k_scan_buckets", "k_scatter", "k_bucket", "k_count",
-                                                   "k_scan_lists", "k_emit",  "k_selfin",  "k_mt19937_fill"};
+                                                   "k_scan_lists", "k_emit",  "k_selfin",  "k_mt19937_fill",
+                                                   "k_graph"};
 
 // Everything a layer's kernels need; passed by value.
 struct LArgs {
@@ -118,6 +122,10 @@ struct LArgs {
   uint32_t S;
   uint32_t tpb;               // frontier tiles per k_sample block
   uint32_t last;              // 1 on the final layer (no next frontier to prepare)
+  // CSL_MODE_GRAPH extras
+  uint32_t graph;             // 0 strict, 1 graph
+  uint8_t* ecnt;              // [S][fcap*P] edges of node i whose source is owned by g
+  uint32_t* srcpos;           // [S][ccap]   position of the first occurrence of an edge's source
 };
 
 constexpr uint32_t SELF_BIT = 0x80000000u;
@@ -293,13 +301,41 @@ __global__ __launch_bounds__(TN) void k_scan(LArgs a) {
       }
       m.next_frontier = nf;
       a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer + 1] = nf;
-      const int kb[CSL_NUM_LISTS] = {K_IN(P, 0),   K_OUT(P, 0), K_OWNED(P, 0), K_SELF(P, 0),
-                                     K_SELF(P, 0), K_TO(P, 0),  K_FROM(P, 0)};
+      uint32_t tot[CSL_NUM_LISTS][CSL_MAX_PARTS];
+      for (int g = 0; g < P; g++) {
+        tot[CSL_IN_NODES][g] = s_tot[K_IN(P, g)];
+        tot[CSL_OUT_NODES][g] = s_tot[K_OUT(P, g)];
+        tot[CSL_OWNED_OUT_NODES][g] = s_tot[K_OWNED(P, g)];
+        tot[CSL_SELF_IDS_IN][g] = s_tot[K_SELF(P, g)];
+        tot[CSL_SELF_IDS_OUT][g] = s_tot[K_SELF(P, g)];
+        if (!a.graph) {
+          tot[CSL_TO_IDS][g] = s_tot[K_TO(P, g)];
+          tot[CSL_FROM_IDS][g] = s_tot[K_FROM(P, g)];
+          tot[CSL_INDPTR][g] = tot[CSL_INDICES][g] = tot[CSL_OWNED_DEGREE][g] = 0;
+        } else {
+          uint32_t fr = 0, to = 0;
+          for (int p = 0; p < P; p++) {
+            m.pair_off[0][g][p] = fr;  // (g -> p) inside slice g's from_ids
+            m.pair_off[1][g][p] = to;  // (p -> g) inside slice g's to_ids
+            fr += s_tot[K_PAIR(P, g, p)];
+            to += s_tot[K_PAIR(P, p, g)];
+          }
+          for (int p = P; p <= CSL_MAX_PARTS; p++) {
+            m.pair_off[0][g][p] = fr;
+            m.pair_off[1][g][p] = to;
+          }
+          tot[CSL_FROM_IDS][g] = fr;
+          tot[CSL_TO_IDS][g] = to;
+          tot[CSL_INDPTR][g] = F ? tot[CSL_OUT_NODES][g] + 1 : 0;
+          tot[CSL_INDICES][g] = s_tot[K_ECNT(P, g)];
+          tot[CSL_OWNED_DEGREE][g] = tot[CSL_OWNED_OUT_NODES][g];
+        }
+      }
       for (int kind = 0; kind < CSL_NUM_LISTS; kind++) {
         uint32_t run = 0;
         for (int g = 0; g < P; g++) {
           m.off[kind][g] = run;
-          run += s_tot[kb[kind] + g];
+          run += tot[kind][g];
         }
         for (int g = P; g <= CSL_MAX_PARTS; g++) m.off[kind][g] = run;
       }
@@ -347,6 +383,8 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
   __shared__ uint32_t s_hb[TN];
   __shared__ uint32_t s_wn[NW];
   __shared__ uint32_t s_cnt[5 * CSL_MAX_PARTS];
+  __shared__ uint32_t s_ec[TN * CSL_MAX_PARTS];                                 // graph: edges per (node, source part)
+  __shared__ uint32_t s_gcnt[CSL_MAX_PARTS + CSL_MAX_PARTS * CSL_MAX_PARTS];    // graph: ECNT[g], PAIR[g][p]
   const uint32_t n = threadIdx.x;
   const uint32_t f = a.fanout, W = a.W;
   const uint32_t P = a.P;
@@ -372,6 +410,10 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
     s_v[n] = v;
     s_ri[n] = ri;
     s_hb[n] = 0;
+    if (a.graph) {
+      for (uint32_t k = n; k < TN * P; k += TN) s_ec[k] = 0;
+      if (n < CSL_MAX_PARTS + CSL_MAX_PARTS * CSL_MAX_PARTS) s_gcnt[n] = 0;
+    }
     __syncthreads();
     {
       uint32_t r = __popcll(bm & lt_mask());
@@ -458,7 +500,9 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
               // bipartite.h:34): it is neither an edge nor new to the frontier
               val[u] = UNSET;
             } else {
-              atomicOr(&s_hb[nnu[u]], 1u << owner(a, val[u]));
+              const uint32_t og = owner(a, val[u]);
+              atomicOr(&s_hb[nnu[u]], 1u << og);
+              if (a.graph) atomicAdd(&s_ec[nnu[u] * P + og], 1u);
               atomicAdd(&s_bh[bucket_of(val[u], nb)], 1u);
             }
           }
@@ -474,7 +518,23 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
     if (act) {
       hb = s_hb[n];
       to = owner(a, v);
+      // graph mode: a node is always an out node of its own slice
+      if (a.graph) hb |= 1u << to;
       a.hasedge[s * a.fcap + i] = hb;
+    }
+    if (a.graph) {
+      for (uint32_t g = 0; g < P; g++) {
+        const uint32_t ec = act ? s_ec[n * P + g] : 0u;  // <= fanout <= 255
+        if (act) a.ecnt[(s * a.fcap + i) * P + g] = (uint8_t)ec;
+        uint32_t x = ec;
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+        if (lane_id() == 0 && x) atomicAdd(&s_gcnt[g], x);
+        const bool hasg = act && ((hb >> g) & 1u) && to != g;
+        for (uint32_t p = 0; p < P; p++) {
+          const uint32_t c_pair = __popcll(__ballot(hasg && to == p));
+          if (lane_id() == 0 && c_pair) atomicAdd(&s_gcnt[CSL_MAX_PARTS + g * CSL_MAX_PARTS + p], c_pair);
+        }
+      }
     }
     for (uint32_t g = 0; g < P; g++) {
       const bool own = act && to == g;
@@ -496,6 +556,13 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
     if (n < 5 * P) {
       const uint32_t kind5 = n / P, g = n - kind5 * P;
       a.tcnt[((size_t)s * a.nk + (K_OUT(P, 0) + kind5 * P + g)) * a.tmax + tile] = s_cnt[kind5 * CSL_MAX_PARTS + g];
+    }
+    if (a.graph) {
+      if (n < P) a.tcnt[((size_t)s * a.nk + K_ECNT(P, n)) * a.tmax + tile] = s_gcnt[n];
+      if (n < P * P) {
+        const uint32_t g = n / P, p = n - g * P;
+        a.tcnt[((size_t)s * a.nk + K_PAIR(P, g, p)) * a.tmax + tile] = s_gcnt[CSL_MAX_PARTS + g * CSL_MAX_PARTS + p];
+      }
     }
   }
   __syncthreads();
@@ -668,6 +735,8 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     } else if (ee.y & SELF_BIT) {
       // only the seed layer can hold a node twice
       if (atomicExch(&h_self[h], ee.y & ~SELF_BIT) != UNSET) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
+      // graph mode: the self entry is a source of its own slice
+      if (a.graph) atomicMin(&h_epos[h], (ee.y & ~SELF_BIT) * W);
     } else {
       atomicMin(&h_epos[h], ee.y);
     }
@@ -684,15 +753,21 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     if (ee.y & SELF_BIT) {
       const uint32_t i = ee.y & ~SELF_BIT;
       const uint32_t c = i * W;
-      const uint32_t newf = epos > c;  // UNSET compares greater than any position
-      cflag[c] = (uint8_t)(newf | (g << 2));
+      if (a.graph) {
+        const uint32_t fe = epos == c;  // epos already includes the self entry
+        cflag[c] = (uint8_t)(fe | (fe << 1) | (g << 2));
+      } else {
+        const uint32_t newf = epos > c;  // UNSET compares greater than any position
+        cflag[c] = (uint8_t)(newf | (g << 2));
+      }
       a.firstpos[s * a.fcap + i] = epos;
     } else {
       const uint32_t c = ee.y;
       const uint32_t self = h_self[h];
       const uint32_t fe = epos == c;
-      const uint32_t newf = fe && (self == UNSET || (unsigned long long)self * W > c);
+      const uint32_t newf = a.graph ? fe : (fe && (self == UNSET || (unsigned long long)self * W > c));
       cflag[c] = (uint8_t)(newf | (fe << 1) | (g << 2));
+      if (a.graph) a.srcpos[(size_t)s * a.ccap + c] = epos;
     }
   };
 #pragma unroll
@@ -893,7 +968,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
         ar[a.list_base[CSL_OUT_NODES] + m.off[CSL_OUT_NODES][g] + p] = (long long)v;
         if (g == to) {
           outrank_to = p;
-        } else {
+        } else if (!a.graph) {
           uint32_t q = r_from[g];
           for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][4 * CSL_MAX_PARTS + g];
           q += TB(K_FROM(P, g));
@@ -915,12 +990,119 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       q += TB(K_OWNED(P, to));
       ar[a.list_base[CSL_OWNED_OUT_NODES] + m.off[CSL_OWNED_OUT_NODES][to] + q] = outrank_to;
     }
-    if ((hb & ~(1u << to)) != 0) {
+    if (!a.graph && (hb & ~(1u << to)) != 0) {
       uint32_t q = r_to;
       for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][3 * CSL_MAX_PARTS + to];
       q += TB(K_TO(P, to));
       ar[a.list_base[CSL_TO_IDS] + m.off[CSL_TO_IDS][to] + q] = outrank_to;
     }
+  }
+#undef TB
+}
+
+// ---- k_graph (CSL_MODE_GRAPH only): what BiPartite::add_edge was meant to build
+// (bipartite.h:55-66) and what slice_layer meant to record per peer
+// (slicer.cpp:40-43): CSR row pointers and local source indices of every slice,
+// the (sender, receiver) boundary lists, and the mean divisor of owned nodes.
+// One thread per frontier node; runs after k_emit (needs the in-node ranks).
+__global__ __launch_bounds__(TN) void k_graph(LArgs a) {
+  uint32_t tile, s;
+  if (!xcd_block(a, tile, s)) return;
+  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  if (tile * TN >= F) return;
+  const uint32_t n = threadIdx.x, w = n >> 6;
+  const uint32_t W = a.W, P = a.P;
+  const csl_layer_meta& m = a.meta[s].layer[a.layer];
+  long long* ar = a.arena + (size_t)s * a.arena_stride;
+  const uint32_t* tc = a.tcnt + (size_t)s * a.nk * a.tmax;
+#define TB(kind) tc[(size_t)(kind)*a.tmax + tile]
+  __shared__ uint32_t s_wo[NW][CSL_MAX_PARTS];                  // out-node counts per wave
+  __shared__ uint32_t s_we[NW][CSL_MAX_PARTS];                  // edge counts per wave
+  __shared__ uint32_t s_wp[NW][CSL_MAX_PARTS * CSL_MAX_PARTS];  // pair counts per wave
+  const uint32_t i = tile * TN + n;
+  const bool act = i < F;
+  uint32_t v = 0, hb = 0, to = 0;
+  if (act) {
+    v = a.fr_in[s * a.fr_in_stride + i];
+    hb = a.hasedge[s * a.fcap + i];
+    to = owner(a, v);
+  }
+  uint32_t r_out[CSL_MAX_PARTS], ec[CSL_MAX_PARTS], r_ec[CSL_MAX_PARTS], r_pair[CSL_MAX_PARTS];
+  const unsigned long long lt = lt_mask();
+#pragma unroll
+  for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
+    r_out[g] = ec[g] = r_ec[g] = r_pair[g] = 0;
+    if (g < P) {
+      const bool has = act && ((hb >> g) & 1u);
+      const unsigned long long b_out = __ballot(has);
+      r_out[g] = __popcll(b_out & lt);
+      ec[g] = act ? (uint32_t)a.ecnt[(s * a.fcap + i) * P + g] : 0u;
+      uint32_t tot;
+      r_ec[g] = wave_excl_scan(ec[g], tot);
+      if (lane_id() == 0) {
+        s_wo[w][g] = __popcll(b_out);
+        s_we[w][g] = tot;
+      }
+      // boundary pair (sender g, receiver p): nodes owned by p with an edge from g
+      for (uint32_t p = 0; p < P; p++) {
+        const unsigned long long b_pair = __ballot(has && to == p && p != g);
+        if (to == p) r_pair[g] = __popcll(b_pair & lt);
+        if (lane_id() == 0) s_wp[w][g * CSL_MAX_PARTS + p] = __popcll(b_pair);
+      }
+    }
+  }
+  __syncthreads();
+  if (!act) return;
+  uint32_t outrank[CSL_MAX_PARTS], rs[CSL_MAX_PARTS];
+  uint32_t deg = 0;
+#pragma unroll
+  for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
+    outrank[g] = rs[g] = 0;
+    if (g < P) {
+      uint32_t p = r_out[g], q = r_ec[g];
+      for (uint32_t ww = 0; ww < w; ww++) {
+        p += s_wo[ww][g];
+        q += s_we[ww][g];
+      }
+      outrank[g] = p + TB(K_OUT(P, g));
+      rs[g] = q + TB(K_ECNT(P, g));  // first index of this node's row in slice g's indices
+      deg += ec[g];
+      if ((hb >> g) & 1u)
+        ar[a.list_base[CSL_INDPTR] + m.off[CSL_INDPTR][g] + outrank[g] + 1] = (long long)(rs[g] + ec[g]);
+      if (i == 0) ar[a.list_base[CSL_INDPTR] + m.off[CSL_INDPTR][g]] = 0;
+    }
+  }
+#pragma unroll
+  for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
+    if (g < P && g != to && ((hb >> g) & 1u)) {
+      uint32_t q = r_pair[g];
+      for (uint32_t ww = 0; ww < w; ww++) q += s_wp[ww][g * CSL_MAX_PARTS + to];
+      q += TB(K_PAIR(P, g, to));
+      ar[a.list_base[CSL_FROM_IDS] + m.off[CSL_FROM_IDS][g] + m.pair_off[0][g][to] + q] = (long long)outrank[g];
+      ar[a.list_base[CSL_TO_IDS] + m.off[CSL_TO_IDS][to] + m.pair_off[1][to][g] + q] = (long long)outrank[to];
+    }
+  }
+  // mean divisor, next to owned_out_nodes (same order as self_ids_*)
+  {
+    const uint32_t q = a.selfpos[s * a.fcap + i] - m.off[CSL_SELF_IDS_OUT][to];
+    ar[a.list_base[CSL_OWNED_DEGREE] + m.off[CSL_OWNED_DEGREE][to] + q] = (long long)deg;
+  }
+  // the node's edges, sampling order: local index of each source inside its slice
+  const size_t cb = (size_t)s * a.ccap + (size_t)i * W;
+  for (uint32_t slot = 1; slot < W; slot++) {
+    const uint32_t val = a.cand[cb + slot];
+    if (val == UNSET) continue;
+    const uint32_t g = owner(a, val);
+    const uint32_t rank = a.crank[(size_t)s * a.ccap + a.srcpos[cb + slot]];
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t gg = 0; gg < CSL_MAX_PARTS; gg++) {
+      if (gg == g) {
+        pos = rs[gg];
+        rs[gg]++;
+      }
+    }
+    ar[a.list_base[CSL_INDICES] + m.off[CSL_INDICES][g] + pos] = (long long)rank;
   }
 #undef TB
 }
@@ -1064,6 +1246,8 @@ struct csl_engine {
   uint32_t* cand = nullptr;
   uint8_t* cflag = nullptr;
   uint32_t* crank = nullptr;
+  uint8_t* ecnt = nullptr;
+  uint32_t* srcpos = nullptr;
   uint2* queue = nullptr;
   uint32_t* nbk = nullptr;
   uint32_t* bcnt = nullptr;
@@ -1288,6 +1472,9 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.wmagic = ((1ull << 40) + a.W - 1) / a.W;
     a.S = (uint32_t)S;
     a.last = l == L - 1 ? 1u : 0u;
+    a.graph = e->cfg.mode == CSL_MODE_GRAPH ? 1u : 0u;
+    a.ecnt = e->ecnt;
+    a.srcpos = e->srcpos;
     const dim3 blk(TN);
     const unsigned tiles_in = (unsigned)((e->fcap[l] + TN - 1) / TN);
     const size_t ccap_l = (size_t)tiles_in * TN * a.W;
@@ -1338,6 +1525,10 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
       Timed t(e, KN_EMIT, e->stream);
       hipLaunchKernelGGL(k_emit, grid_in, blk, 0, e->stream, a);
     }
+    if (a.graph) {
+      Timed t(e, KN_EDGES, e->stream);
+      hipLaunchKernelGGL(k_graph, grid_in, blk, 0, e->stream, a);
+    }
     {
       Timed t(e, KN_SELFIN, e->stream);
       hipLaunchKernelGGL(k_selfin, grid_in, blk, 0, e->stream, a);
@@ -1372,7 +1563,8 @@ void csl_destroy(csl_engine* e) {
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   void* ptrs[] = {e->rowinfo, e->indices, e->wl,      e->nodes, e->seedbuf, e->ring,  e->mt_state, e->rngpos,
                   e->rngbase, e->ninfo,   e->hasedge, e->selfpos, e->firstpos, e->cand, e->cflag, e->crank,
-                  e->queue,   e->nbk,     e->bcnt,    e->bcur,    e->tcnt,     e->fsize, e->meta, e->desc_dev};
+                  e->queue,   e->nbk,     e->bcnt,    e->bcur,    e->tcnt,     e->fsize, e->meta, e->desc_dev,
+                  e->ecnt,    e->srcpos};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (int l = 0; l <= CSL_MAX_LAYERS; l++)
@@ -1452,7 +1644,7 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
     if (c >= 0x80000000ull) return fail(CSL_E_INVALID, "candidate positions exceed 31 bits");
   }
   e->tmax = (uint32_t)((e->fcap_max + TN - 1) / TN);
-  e->nk = (uint32_t)NKINDS(P);
+  e->nk = (uint32_t)NKINDS(P, cfg->mode == CSL_MODE_GRAPH);
   // ---- per-stream scratch
   for (int l = 0; l <= L; l++) DMALLOC(e->fr[l], (size_t)e->slots * S * e->fcap[l]);  // [slot][S][fcap]
   DMALLOC(e->ninfo, (size_t)S * e->fcap_max);
@@ -1462,6 +1654,10 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   DMALLOC(e->cand, (size_t)S * e->ccap_max);
   DMALLOC(e->cflag, (size_t)S * e->ccap_max);
   DMALLOC(e->crank, (size_t)S * e->ccap_max);
+  if (cfg->mode == CSL_MODE_GRAPH) {
+    DMALLOC(e->ecnt, (size_t)S * e->fcap_max * P);
+    DMALLOC(e->srcpos, (size_t)S * e->ccap_max);
+  }
   DMALLOC(e->queue, (size_t)S * e->ccap_max);
   e->nbmax = (uint32_t)((e->ccap_max + QMEAN - 1) / QMEAN);
   if (e->nbmax < 1) e->nbmax = 1;
@@ -1496,6 +1692,19 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
     cap[CSL_SELF_IDS_OUT] = F;
     cap[CSL_TO_IDS] = F;
     cap[CSL_FROM_IDS] = outs;
+    cap[CSL_INDPTR] = cap[CSL_INDICES] = cap[CSL_OWNED_DEGREE] = 0;
+    if (cfg->mode == CSL_MODE_GRAPH) {
+      // every owned node is an in node and an out node of its slice
+      size_t outs_g = F * (size_t)(P < (int)f + 1 ? P : (int)f + 1);
+      if (outs_g > edges + F) outs_g = edges + F;
+      cap[CSL_IN_NODES] = edges + F;
+      cap[CSL_OUT_NODES] = outs_g;
+      cap[CSL_TO_IDS] = outs;
+      cap[CSL_FROM_IDS] = outs;
+      cap[CSL_INDPTR] = outs_g + (size_t)P;
+      cap[CSL_INDICES] = edges;
+      cap[CSL_OWNED_DEGREE] = F;
+    }
     size_t o = 0;
     for (int k = 0; k < CSL_NUM_LISTS; k++) {
       e->list_base[l][k] = o;
@@ -1541,6 +1750,7 @@ int csl_create(const csl_config* cfg, csl_engine** out) {
   if (cfg->n_streams < 1 || cfg->n_streams > 1024) return fail(CSL_E_INVALID, "n_streams must be 1..1024");
   if (cfg->n_slots < 1 || cfg->n_slots > 16) return fail(CSL_E_INVALID, "n_slots must be 1..16");
   if (cfg->max_batch < 1) return fail(CSL_E_INVALID, "max_batch must be >= 1");
+  if (cfg->mode != CSL_MODE_STRICT && cfg->mode != CSL_MODE_GRAPH) return fail(CSL_E_INVALID, "unknown mode %d", cfg->mode);
   if (!cfg->indptr || (!cfg->indices && cfg->num_edges > 0)) return fail(CSL_E_INVALID, "graph arrays missing");
   // the reference keeps ids and row offsets in `int` (slicer.cpp:9,16;
   // bipartite.h:55): bit-exact behaviour is only defined below 2^31

@@ -215,6 +215,13 @@ typedef struct orc {
   vec nbr_flat[ORC_MAX_LAYERS];
   uint64_t layer_draws[ORC_MAX_LAYERS];
   uint64_t sampled_edges; /* non-self entries pushed by neighbour_sample, last sample */
+  /* graph ("fixed") mode, see orc_sample_graph below */
+  struct gbp {
+    vec in_nodes, out_nodes, indptr, indices, owned_out_nodes, self_ids_in, self_ids_out, owned_degree;
+    vec from_ids[ORC_MAX_PARTS], to_ids[ORC_MAX_PARTS];
+  } glayers[ORC_MAX_LAYERS][ORC_MAX_PARTS];
+  int* gmask; /* scratch: in-node rank + 1 per node, one slice at a time */
+  int* grow;  /* scratch: out-node rank + 1 per node */
 } orc;
 
 static inline int orc_workload(const orc* o, int64_t v) {
@@ -337,12 +344,127 @@ void orc_destroy(orc* o) {
     vec_free(&o->nbr_flat[l]);
   }
   for (int l = 0; l <= ORC_MAX_LAYERS; l++) vec_free(&o->frontier[l]);
+  for (int l = 0; l < ORC_MAX_LAYERS; l++)
+    for (int g = 0; g < ORC_MAX_PARTS; g++) {
+      struct gbp* b = &o->glayers[l][g];
+      vec_free(&b->in_nodes); vec_free(&b->out_nodes); vec_free(&b->indptr); vec_free(&b->indices);
+      vec_free(&b->owned_out_nodes); vec_free(&b->self_ids_in); vec_free(&b->self_ids_out);
+      vec_free(&b->owned_degree);
+      for (int p = 0; p < ORC_MAX_PARTS; p++) { vec_free(&b->from_ids[p]); vec_free(&b->to_ids[p]); }
+    }
+  free(o->gmask);
+  free(o->grow);
   dupr_free(&o->dr);
   dupr_free(&o->out_dr);
   vec_free(&o->in);
   vec_free(&o->out);
   vec_free(&o->neighbors);
   free(o);
+}
+
+/* ------------------------------------------------------------------ graph mode
+ * NOT in the reference: the object the reference *meant* to export (a real CSR
+ * per slice; its BiPartite::add_edge never builds one, bipartite.h:55-66, and
+ * from_ids/to_ids are only filled at the own index, slicer.cpp:41-42).  This is
+ * the specification of the engine's CSL_MODE_GRAPH, restated sequentially so
+ * the HIP path can be checked bit for bit.  Sampling (rng stream, candidate
+ * order, next frontier) is exactly the strict path's.  Per layer and slice g
+ * (g owns the SOURCE nodes of its edges):
+ *   in_nodes[g]   first-occurrence order over { self entry of every frontier
+ *                 node owned by g } U { sampled neighbours owned by g }
+ *   out_nodes[g]  frontier nodes owned by g or with >= 1 edge from a g-owned
+ *                 source, frontier order
+ *   indptr/indices[g]  CSR over out_nodes[g]; indices = in-node rank of each
+ *                 edge's source, sampling order (sampled self loops dropped)
+ *   owned_out_nodes[g] = self_ids_out[g]  rows of out_nodes[g] owned by g
+ *   self_ids_in[g]     their ranks in in_nodes[g]
+ *   owned_degree[g]    their edge counts over ALL slices (mean divisor)
+ *   from_ids[g][p]     rows of out_nodes[g] owned by p != g (partials to send)
+ *   to_ids[p][g]       rows of out_nodes[p] they are added to, same order
+ */
+static void orc_graph_layer(orc* o, const vec* in, int l) {
+  const int P = o->n_parts;
+  const vec* counts = &o->nbr_counts[l];
+  const vec* flat = &o->nbr_flat[l];
+  for (int g = 0; g < P; g++) {
+    struct gbp* b = &o->glayers[l][g];
+    vec_clear(&b->in_nodes); vec_clear(&b->out_nodes); vec_clear(&b->indptr); vec_clear(&b->indices);
+    vec_clear(&b->owned_out_nodes); vec_clear(&b->self_ids_in); vec_clear(&b->self_ids_out);
+    vec_clear(&b->owned_degree);
+    for (int p = 0; p < P; p++) { vec_clear(&b->from_ids[p]); vec_clear(&b->to_ids[p]); }
+  }
+  for (int g = 0; g < P; g++) {
+    struct gbp* b = &o->glayers[l][g];
+    /* pass 1: in_nodes ranks */
+    size_t k = 0;
+    for (size_t i = 0; i < in->n; i++) {
+      int64_t nd1 = in->p[i];
+      size_t c = (size_t)counts->p[i];
+      for (size_t j = 0; j < c; j++) {
+        int64_t nd2 = flat->p[k + j];
+        int take = (j == 0) ? (orc_workload(o, nd1) == g) : (nd2 != nd1 && orc_workload(o, nd2) == g);
+        if (take && o->gmask[nd2] == 0) {
+          vec_push(&b->in_nodes, nd2);
+          o->gmask[nd2] = (int)b->in_nodes.n;
+        }
+      }
+      k += c;
+    }
+    /* pass 2: rows */
+    k = 0;
+    vec_push(&b->indptr, 0);
+    for (size_t i = 0; i < in->n; i++) {
+      int64_t nd1 = in->p[i];
+      size_t c = (size_t)counts->p[i];
+      int own = orc_workload(o, nd1) == g;
+      size_t e0 = b->indices.n;
+      for (size_t j = 1; j < c; j++) {
+        int64_t nd2 = flat->p[k + j];
+        if (nd2 != nd1 && orc_workload(o, nd2) == g) vec_push(&b->indices, o->gmask[nd2] - 1);
+      }
+      if (own || b->indices.n > e0) {
+        vec_push(&b->out_nodes, nd1);
+        vec_push(&b->indptr, (int64_t)b->indices.n);
+        if (own) {
+          vec_push(&b->owned_out_nodes, (int64_t)b->out_nodes.n - 1);
+          vec_push(&b->self_ids_out, (int64_t)b->out_nodes.n - 1);
+          vec_push(&b->self_ids_in, o->gmask[nd1] - 1);
+          int64_t deg = 0;
+          for (size_t j = 1; j < c; j++) deg += flat->p[k + j] != nd1;
+          vec_push(&b->owned_degree, deg);
+        }
+      }
+      k += c;
+    }
+    for (size_t q = 0; q < b->in_nodes.n; q++) o->gmask[b->in_nodes.p[q]] = 0;
+  }
+  /* pass 3: boundary lists, per ordered pair (sender g, receiver p) */
+  for (int p = 0; p < P; p++) {
+    struct gbp* bp = &o->glayers[l][p];
+    for (size_t r = 0; r < bp->out_nodes.n; r++) o->grow[bp->out_nodes.p[r]] = (int)r + 1;
+    for (int g = 0; g < P; g++) {
+      if (g == p) continue;
+      struct gbp* bg = &o->glayers[l][g];
+      for (size_t r = 0; r < bg->out_nodes.n; r++) {
+        int64_t nd1 = bg->out_nodes.p[r];
+        if (orc_workload(o, nd1) != p) continue;
+        vec_push(&bg->from_ids[p], (int64_t)r);
+        vec_push(&bp->to_ids[g], (int64_t)o->grow[nd1] - 1);
+      }
+    }
+    for (size_t r = 0; r < bp->out_nodes.n; r++) o->grow[bp->out_nodes.p[r]] = 0;
+  }
+}
+
+int orc_sample_graph(orc* o, const int64_t* seeds, int64_t n) {
+  if (!o->capture) return -1; /* needs the traversal record */
+  if (!o->gmask) {
+    o->gmask = (int*)calloc((size_t)(o->num_nodes > 0 ? o->num_nodes : 1), sizeof(int));
+    o->grow = (int*)calloc((size_t)(o->num_nodes > 0 ? o->num_nodes : 1), sizeof(int));
+  }
+  orc_sample(o, seeds, n); /* same rng consumption, same frontiers */
+  for (int l = 0; l < o->n_layers; l++) orc_graph_layer(o, &o->frontier[l], l);
+  return 0;
 }
 
 /* ------------------------------------------------------------------ accessors */
@@ -358,7 +480,18 @@ enum {
   ORC_TO_IDS = 8,   /* sub = index */
   ORC_FRONTIER = 9, /* part ignored; layer 0..n_layers (capture only) */
   ORC_NBR_COUNTS = 10,
-  ORC_NBR_FLAT = 11
+  ORC_NBR_FLAT = 11,
+  /* graph mode (orc_sample_graph) */
+  ORC_G_IN_NODES = 100,
+  ORC_G_OUT_NODES = 101,
+  ORC_G_INDPTR = 102,
+  ORC_G_INDICES = 103,
+  ORC_G_OWNED_OUT_NODES = 104,
+  ORC_G_SELF_IDS_IN = 105,
+  ORC_G_SELF_IDS_OUT = 106,
+  ORC_G_OWNED_DEGREE = 107,
+  ORC_G_FROM_IDS = 108, /* sub = receiver */
+  ORC_G_TO_IDS = 109    /* sub = sender */
 };
 
 static const vec* orc_pick(const orc* o, int layer, int part, int which, int sub) {
@@ -368,6 +501,22 @@ static const vec* orc_pick(const orc* o, int layer, int part, int which, int sub
   if (which == ORC_NBR_COUNTS) return &o->nbr_counts[layer];
   if (which == ORC_NBR_FLAT) return &o->nbr_flat[layer];
   if (part < 0 || part >= o->n_parts) return &empty;
+  if (which >= ORC_G_IN_NODES) {
+    const struct gbp* gb = &o->glayers[layer][part];
+    switch (which) {
+      case ORC_G_IN_NODES: return &gb->in_nodes;
+      case ORC_G_OUT_NODES: return &gb->out_nodes;
+      case ORC_G_INDPTR: return &gb->indptr;
+      case ORC_G_INDICES: return &gb->indices;
+      case ORC_G_OWNED_OUT_NODES: return &gb->owned_out_nodes;
+      case ORC_G_SELF_IDS_IN: return &gb->self_ids_in;
+      case ORC_G_SELF_IDS_OUT: return &gb->self_ids_out;
+      case ORC_G_OWNED_DEGREE: return &gb->owned_degree;
+      case ORC_G_FROM_IDS: return (sub >= 0 && sub < o->n_parts) ? &gb->from_ids[sub] : &empty;
+      case ORC_G_TO_IDS: return (sub >= 0 && sub < o->n_parts) ? &gb->to_ids[sub] : &empty;
+    }
+    return &empty;
+  }
   const bipartite* b = &o->layers[layer][part];
   switch (which) {
     case ORC_IN_NODES: return &b->in_nodes;

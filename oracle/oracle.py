@@ -16,6 +16,9 @@ LIST_NAMES = ["in_nodes", "indptr", "out_nodes", "owned_out_nodes", "indices",
               "self_ids_in", "self_ids_out"]
 IN_NODES, INDPTR, OUT_NODES, OWNED_OUT_NODES, INDICES, SELF_IDS_IN, SELF_IDS_OUT = range(7)
 FROM_IDS, TO_IDS, FRONTIER, NBR_COUNTS, NBR_FLAT = 7, 8, 9, 10, 11
+GRAPH_LISTS = {"in_nodes": 100, "out_nodes": 101, "indptr": 102, "indices": 103, "owned_out_nodes": 104,
+               "self_ids_in": 105, "self_ids_out": 106, "owned_degree": 107}
+G_FROM_IDS, G_TO_IDS = 108, 109
 
 _lib = None
 
@@ -36,6 +39,7 @@ def lib():
         L.orc_create.argtypes = [p64, p64, C.c_int64, p32, C.c_int, C.c_int, p32, C.c_uint32, C.c_int]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_sample.argtypes = [C.c_void_p, p64, C.c_int64]
+        L.orc_sample_graph.argtypes = [C.c_void_p, p64, C.c_int64]
         L.orc_list_len.restype = C.c_int64
         L.orc_list_len.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_list_ptr.restype = p64
@@ -125,6 +129,32 @@ class Oracle:
         out["sampled_edges"] = int(lib().orc_sampled_edges(self._h))
         out["draws_total"] = int(lib().orc_draws_total(self._h))
         return out
+
+
+def _sample_graph(self, seeds):
+    """Graph ("fixed") mode: real slice CSR + per-peer boundary lists (the engine's
+    CSL_MODE_GRAPH specification, see orc_sample_graph in cslicer_oracle.c)."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+    if lib().orc_sample_graph(self._h, _p64(seeds), seeds.shape[0]) != 0:
+        raise RuntimeError("orc_sample_graph needs capture=True")
+    out = {"layers": [], "frontier": []}
+    for l in range(self.n_layers):
+        parts = []
+        for g in range(self.n_parts):
+            bp = {name: self._get(l, g, code) for name, code in GRAPH_LISTS.items()}
+            bp["from_ids"] = [self._get(l, g, G_FROM_IDS, p) for p in range(self.n_parts)]
+            bp["to_ids"] = [self._get(l, g, G_TO_IDS, p) for p in range(self.n_parts)]
+            bp["gpu_id"] = g
+            parts.append(bp)
+        out["layers"].append(parts)
+    for l in range(self.n_layers + 1):
+        out["frontier"].append(self._get(l, 0, FRONTIER))
+    out["sampled_edges"] = int(lib().orc_sampled_edges(self._h))
+    out["draws_total"] = int(lib().orc_draws_total(self._h))
+    return out
+
+
+Oracle.sample_graph = _sample_graph
 
 
 def bench(indptr, indices, batches, n_parts=4, fanouts=(10, 10, 10), workload=None, seed=5489,

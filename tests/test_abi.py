@@ -32,11 +32,12 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_struct_layout():
     L = _abi.load()
     assert L.csl_abi_version() == _abi.ABI_VERSION
-    # csl_layer_meta: 4 u32 + 7*(8+1) u32
-    assert C.sizeof(_abi.LayerMeta) == 4 * (4 + 7 * 9)
+    # csl_layer_meta: 4 u32 + 10*(8+1) u32 offsets + 2*8*(8+1) pair offsets
+    assert C.sizeof(_abi.LayerMeta) == 4 * (4 + 10 * 9 + 2 * 8 * 9)
     assert C.sizeof(_abi.SampleMeta) == 8 + 16 + 4 * C.sizeof(_abi.LayerMeta)
     assert L.csl_kernel_name(3).decode() == "k_sample"
-    assert L.csl_kernel_name(_abi.NUM_KERNELS - 1).decode() == "k_mt19937_fill"
+    names = [L.csl_kernel_name(k).decode() for k in range(_abi.NUM_KERNELS)]
+    assert "k_mt19937_fill" in names and "k_graph" in names and len(set(names)) == _abi.NUM_KERNELS
 
 
 def test_header_cites_reference_interfaces():

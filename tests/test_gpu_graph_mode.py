@@ -1,0 +1,153 @@
+"""CSL_MODE_GRAPH: the object the reference meant to export (real slice CSR, per-peer boundary
+lists).  The reference itself never builds it (bipartite.h:55-66, slicer.cpp:41-42), so parity is
+against the sequential specification in the oracle (orc_sample_graph): bit-exact, plus structural
+invariants that tie the graph object back to the strict object and to the input graph."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GKEYS = ["in_nodes", "out_nodes", "indptr", "indices", "owned_out_nodes", "self_ids_in", "self_ids_out",
+         "owned_degree"]
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from cslicer import _abi
+    _abi.load()
+    return _abi
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def assert_same_graph(got, want, what=""):
+    assert len(got["layers"]) == len(want["layers"])
+    for l, (gl, wl) in enumerate(zip(got["layers"], want["layers"])):
+        for p, (gb, wb) in enumerate(zip(gl, wl)):
+            tag = "%s layer %d part %d " % (what, l, p)
+            for k in GKEYS:
+                np.testing.assert_array_equal(gb[k], wb[k], err_msg=tag + k)
+            for j in range(len(wl)):
+                np.testing.assert_array_equal(gb["from_ids"][j], wb["from_ids"][j], err_msg=tag + "from_ids[%d]" % j)
+                np.testing.assert_array_equal(gb["to_ids"][j], wb["to_ids"][j], err_msg=tag + "to_ids[%d]" % j)
+    for l, (a, b) in enumerate(zip(got["frontier"], want["frontier"])):
+        np.testing.assert_array_equal(a, b, err_msg="%s frontier[%d]" % (what, l))
+
+
+def check_graph_invariants(d, indptr, indices, P):
+    """Every edge of the slice CSRs is a real edge of the input graph, boundary lists pair up."""
+    for l, parts in enumerate(d["layers"]):
+        fr = d["frontier"][l]
+        edges = 0
+        for g, bp in enumerate(parts):
+            ip, ix = bp["indptr"], bp["indices"]
+            assert ip[0] == 0 and len(ip) == len(bp["out_nodes"]) + 1 and ip[-1] == len(ix)
+            assert (np.diff(ip) >= 0).all()
+            assert ((ix >= 0) & (ix < len(bp["in_nodes"]))).all()
+            edges += len(ix)
+            src = bp["in_nodes"][ix]
+            dst = np.repeat(bp["out_nodes"], np.diff(ip))
+            assert (src % P == g).all()
+            for k in range(0, len(src), max(1, len(src) // 200)):   # spot-check real adjacency
+                row = indices[indptr[dst[k]]:indptr[dst[k] + 1]]
+                assert src[k] in row
+            own = bp["owned_out_nodes"]
+            np.testing.assert_array_equal(bp["out_nodes"][own], fr[fr % P == g])
+            np.testing.assert_array_equal(bp["in_nodes"][bp["self_ids_in"]], fr[fr % P == g])
+            np.testing.assert_array_equal(bp["self_ids_out"], own)
+        for g in range(P):
+            for p in range(P):
+                a, b = parts[g]["from_ids"][p], parts[p]["to_ids"][g]
+                assert len(a) == len(b)
+                if g == p:
+                    assert len(a) == 0
+                    continue
+                np.testing.assert_array_equal(parts[g]["out_nodes"][a], parts[p]["out_nodes"][b])
+                assert (parts[g]["out_nodes"][a] % P == p).all()
+        # total degree of owned nodes == all edges of the layer
+        assert sum(int(bp["owned_degree"].sum()) for bp in parts) == edges
+
+
+CONFIGS = [
+    (3000, 20.0, 4, (10, 10, 10), 64, 2),
+    (5000, 6.0, 1, (15, 10, 5), 100, 1),
+    (4000, 25.0, 8, (15, 10, 5), 256, 2),
+    (4000, 25.0, 3, (5, 5), 200, 3),
+    (20000, 50.5, 4, (15, 10, 5), 1024, 2),
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[str(c) for c in CONFIGS])
+def test_graph_mode_matches_specification(abi, orc, cfg):
+    from cslicer import l0
+    n, deg, P, fan, B, S = cfg
+    indptr, indices = l0.synth_graph(n, deg, seed=n + P)
+    perm = np.random.default_rng(3).permutation(n)
+    e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, mode=abi.MODE_GRAPH)
+    e.set_nodes(perm)
+    oracles = [orc.Oracle(indptr, indices, n_parts=P, fanouts=fan) for _ in range(S)]
+    for r in range(2):
+        e.submit_round(r * S, B, S)
+        for s in range(S):
+            seeds = perm[(r * S + s) * B:(r * S + s + 1) * B]
+            want = oracles[s].sample_graph(seeds)
+            got = e.graph_dict(s)
+            assert_same_graph(got, want, what="round %d stream %d" % (r, s))
+            assert got["draws_total"] == want["draws_total"]
+            if P > 1 or True:
+                check_graph_invariants(got, indptr, indices, P)
+    e.close()
+
+
+def test_graph_mode_golden_graphs(abi, orc):
+    # the reference's golden INPUTS (self loops, multi-edges, isolated nodes, degree 9/10/11):
+    # sampling and frontiers must still be the reference's, the graph object the specification's
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_util import UNIQUE_SEED_CASES, load_case
+    for case in UNIQUE_SEED_CASES:
+        indptr, indices, batches = load_case(case)
+        mb = max(len(b["seeds"]) for b in batches)
+        e = abi.Engine(indptr, indices, max_batch=mb, mode=abi.MODE_GRAPH)
+        o = orc.Oracle(indptr, indices)
+        for b, gold in enumerate(batches):
+            e.submit_seeds([gold["seeds"]])
+            got = e.graph_dict(0)
+            assert_same_graph(got, o.sample_graph(gold["seeds"]), what="%s batch %d" % (case, b))
+            for l in range(4):   # frontiers are the unmodified reference's
+                np.testing.assert_array_equal(got["frontier"][l], gold["frontier"][l])
+        e.close()
+
+
+def test_strict_and_graph_share_sampling(abi):
+    from cslicer import l0
+    indptr, indices = l0.synth_graph(6000, 30.0, seed=4)
+    perm = np.random.default_rng(9).permutation(6000)
+    es = abi.Engine(indptr, indices, max_batch=128, n_streams=2)
+    eg = abi.Engine(indptr, indices, max_batch=128, n_streams=2, mode=abi.MODE_GRAPH)
+    for e in (es, eg):
+        e.set_nodes(perm)
+        e.submit_round(0, 128, 2)
+    for s in range(2):
+        ds, dg = es.sample_dict(s), eg.graph_dict(s)
+        for l in range(4):
+            np.testing.assert_array_equal(ds["frontier"][l], dg["frontier"][l])
+        assert ds["draws_total"] == dg["draws_total"]
+        for l in range(3):
+            for g in range(4):
+                a, b = ds["layers"][l][g], dg["layers"][l][g]
+                # graph in_nodes = strict in_nodes + the slice's own frontier nodes (as sets: a self
+                # entry can move a node's first occurrence forward)
+                fr = ds["frontier"][l]
+                want = np.union1d(a["in_nodes"], fr[fr % 4 == g])
+                np.testing.assert_array_equal(np.sort(b["in_nodes"]), want)
+                # strict out_nodes are a subsequence of graph out_nodes
+                keep = np.isin(b["out_nodes"], a["out_nodes"])
+                np.testing.assert_array_equal(b["out_nodes"][keep], a["out_nodes"])
+    es.close()
+    eg.close()
