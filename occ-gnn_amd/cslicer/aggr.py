@@ -1,0 +1,151 @@
+"""Split-parallel aggregation ops over the slices: ctypes binding of include/cslicer_aggr.h
+plus torch.autograd wrappers.  torch only provides device memory, streams and autograd
+plumbing; the work is done by the HIP kernels in occ-gnn_amd/csrc/aggregate.hip.
+
+Reference semantics: python/data/bipartite.py:61-99 (gather, self_gather, pull_for_remotes,
+push_from_remotes), src/gnn/sage.cu:7-28, src/gnn/dist_sage.cu:193-199.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+
+SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
+           "csl_scatter_add_rows_f32", "csl_div_rows_f32"]
+_ready = False
+
+
+def _lib():
+    global _ready
+    L = _abi.load()
+    if not _ready:
+        vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
+        L.csl_spmm_sum_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, i32, vp]
+        L.csl_spmm_sum_bwd_f32.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp]
+        L.csl_gather_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
+        L.csl_scatter_add_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
+        L.csl_div_rows_f32.argtypes = [vp, i64, vp, i64, i32, vp]
+        _ready = True
+    return L
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(rc, what):
+    if rc < 0:
+        raise _abi.CslError(rc, what + " failed")
+
+
+def _f32(x):
+    if x.dtype != torch.float32 or not x.is_cuda:
+        raise TypeError("expected a float32 CUDA tensor")
+    return x if x.stride(-1) == 1 else x.contiguous()
+
+
+def _i64(x):
+    if x.dtype != torch.int64 or not x.is_cuda:
+        raise TypeError("expected an int64 CUDA tensor")
+    return x.contiguous()
+
+
+def spmm_sum(indptr, indices, x, n_rows, rows=None, out=None):
+    """out[row] = sum of x[indices[e]] over the row's edges (BipartiteGraph.gather, sum form).
+    rows: optional int64 list of the rows to compute (others untouched)."""
+    x = _f32(x)
+    H = x.shape[1]
+    if out is None:
+        out = torch.empty((n_rows, H), dtype=torch.float32, device=x.device)
+        if rows is not None:
+            out.zero_()
+    n = n_rows if rows is None else rows.numel()
+    _chk(_lib().csl_spmm_sum_f32(_p(_i64(indptr)), _p(_i64(indices)), _p(rows) if rows is not None else C.c_void_p(0),
+                                 n, _p(x), x.stride(0), _p(out), out.stride(0), H, _stream()), "csl_spmm_sum_f32")
+    return out
+
+
+def spmm_sum_bwd(indptr, indices, grad_out, n_src):
+    g = _f32(grad_out)
+    gx = torch.zeros((n_src, g.shape[1]), dtype=torch.float32, device=g.device)
+    _chk(_lib().csl_spmm_sum_bwd_f32(_p(_i64(indptr)), _p(_i64(indices)), g.shape[0], _p(g), g.stride(0), _p(gx),
+                                     gx.stride(0), g.shape[1], _stream()), "csl_spmm_sum_bwd_f32")
+    return gx
+
+
+def gather_rows(src, idx):
+    """dst[k] = src[idx[k]] (zero row for idx -1): pull_for_remotes / self_gather."""
+    src = _f32(src)
+    idx = _i64(idx)
+    dst = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
+    _chk(_lib().csl_gather_rows_f32(_p(src), src.stride(0), _p(idx), idx.numel(), _p(dst), dst.stride(0),
+                                    src.shape[1], _stream()), "csl_gather_rows_f32")
+    return dst
+
+
+def scatter_add_rows_(dst, idx, src):
+    """dst[idx[k]] += src[k] in place (idx unique): push_from_remotes / mergeKernel."""
+    src = _f32(src)
+    idx = _i64(idx)
+    if dst.stride(-1) != 1:
+        raise ValueError("dst must be row-contiguous")
+    _chk(_lib().csl_scatter_add_rows_f32(_p(dst), dst.stride(0), _p(idx), idx.numel(), _p(src), src.stride(0),
+                                         src.shape[1], _stream()), "csl_scatter_add_rows_f32")
+    return dst
+
+
+def div_rows_(x, deg):
+    """x[k] /= max(deg[k], 1) in place."""
+    _chk(_lib().csl_div_rows_f32(_p(x), x.stride(0), _p(_i64(deg)), x.shape[0], x.shape[1], _stream()),
+         "csl_div_rows_f32")
+    return x
+
+
+class SpmmSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, indptr, indices, n_rows):
+        ctx.save_for_backward(indptr, indices)
+        ctx.n_src = x.shape[0]
+        return spmm_sum(indptr, indices, x, n_rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        indptr, indices = ctx.saved_tensors
+        return spmm_sum_bwd(indptr, indices, g.contiguous(), ctx.n_src), None, None, None
+
+
+class GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx):
+        ctx.save_for_backward(idx)
+        ctx.n_src = src.shape[0]
+        return gather_rows(src, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gs = torch.zeros((ctx.n_src, g.shape[1]), dtype=torch.float32, device=g.device)
+        scatter_add_rows_(gs, idx, g.contiguous())
+        return gs, None
+
+
+class ScatterAddRows(torch.autograd.Function):
+    """out = dst with src rows added at idx.  dst is updated in place (marked dirty)."""
+
+    @staticmethod
+    def forward(ctx, dst, idx, src):
+        ctx.save_for_backward(idx)
+        ctx.mark_dirty(dst)
+        scatter_add_rows_(dst, idx, src)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = g.contiguous()
+        return g, None, gather_rows(g, idx)

@@ -1,0 +1,217 @@
+"""Split-parallel GraphSAGE over the slices (CSL_MODE_GRAPH), torch + HIP kernels, no DGL.
+
+Counterpart of the reference's Python consumer:
+  DistSageConv.forward          python/layers/dist_sageconv.py:42-84
+  DistSAGEModel                 python/models/factory.py:7-56
+  BipartiteGraph ops            python/data/bipartite.py:61-99
+  DistGraphConv (4x4 merge)     python/batch_slice_multi_gpu.py:40-76
+
+Part g (one GPU) owns the nodes with workload g and their features.  Per GNN layer, on part g:
+
+  agg   = SUM over the slice's CSR of source features        (local: sources are owned by g)
+  send  = agg[from_ids[g][p]]  -> part p                     (partials for nodes owned by p)
+  agg[to_ids[g][p]] += recv from p                           (boundary merge)
+  h     = Linear(concat(x[self_ids_in], agg[owned] / degree))
+
+The reference averages per-GPU means (`(local+remote)/2`, bipartite.py:98), which is not the
+mean over the sampled neighbours; here partial SUMS are merged and divided once by the true
+sampled degree.
+
+Layer chaining needs no index translation: the rows a layer produces for part g (owned frontier
+nodes, frontier order) are exactly, in order, the in_nodes of part g one hop closer to the seeds.
+
+Every rank slices the SAME minibatch with its own engine (the slicer is deterministic and ~40x
+faster than the training step): topology is recomputed, never communicated; only boundary
+partial sums cross xGMI (one all-to-all per layer, on a side stream, overlapped with the rows
+that do not leave the GPU).
+"""
+import torch
+import torch.nn as nn
+
+from . import _abi, aggr
+
+
+class _DevArray(object):
+    """Zero-copy view of engine memory for torch.as_tensor (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, n, typestr="<i8"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _view_i64(ptr, n, device):
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64, device=device)
+    return torch.as_tensor(_DevArray(ptr, n), device=device)
+
+
+class Slice(object):
+    """One BiPartite of graph mode on the device: int64 tensors that alias the engine's arena."""
+
+    __slots__ = ("part", "n_parts", "in_nodes", "out_nodes", "indptr", "indices", "owned_out_nodes",
+                 "self_ids_in", "owned_degree", "from_ids", "to_ids", "n_in", "n_out", "n_owned")
+
+
+def slices_of(eng, stream=0, slot=0, parts=None, device=None):
+    """All layers x parts of one sample as `Slice`s (layer 0 = hop from the seeds).
+    parts: iterable of part ids to materialise (default all)."""
+    if eng.mode != _abi.MODE_GRAPH:
+        raise ValueError("splitgnn needs an engine created with mode=MODE_GRAPH")
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    m = eng.meta(stream, slot)          # waits for the round that filled the slot
+    P = eng.n_parts
+    parts = range(P) if parts is None else parts
+    out = []
+    for l in range(eng.n_layers):
+        lm = m.layer[l]
+        base = {k: eng.list_device_ptr(l, k, stream, slot) for k in range(_abi.NUM_LISTS)}
+
+        def seg(kind, g, lo=None, hi=None):
+            a = int(lm.off[kind][g]) if lo is None else lo
+            b = int(lm.off[kind][g + 1]) if hi is None else hi
+            return _view_i64(base[kind] + 8 * a, b - a, device)
+
+        row = {}
+        for g in parts:
+            s = Slice()
+            s.part, s.n_parts = g, P
+            s.in_nodes = seg(_abi.IN_NODES, g)
+            s.out_nodes = seg(_abi.OUT_NODES, g)
+            s.indptr = seg(_abi.INDPTR, g)
+            s.indices = seg(_abi.INDICES, g)
+            s.owned_out_nodes = seg(_abi.OWNED_OUT_NODES, g)
+            s.self_ids_in = seg(_abi.SELF_IDS_IN, g)
+            s.owned_degree = seg(_abi.OWNED_DEGREE, g)
+            f0, t0 = int(lm.off[_abi.FROM_IDS][g]), int(lm.off[_abi.TO_IDS][g])
+            s.from_ids = [seg(_abi.FROM_IDS, g, f0 + int(lm.pair_off[0][g][p]), f0 + int(lm.pair_off[0][g][p + 1]))
+                          for p in range(P)]
+            s.to_ids = [seg(_abi.TO_IDS, g, t0 + int(lm.pair_off[1][g][p]), t0 + int(lm.pair_off[1][g][p + 1]))
+                        for p in range(P)]
+            s.n_in, s.n_out, s.n_owned = s.in_nodes.numel(), s.out_nodes.numel(), s.owned_out_nodes.numel()
+            row[g] = s
+        out.append(row)
+    return out
+
+
+class DistSageConv(nn.Module):
+    """dist_sageconv.py:8-84: concat(self, aggregated neighbours) -> Linear(2*in, out)."""
+
+    def __init__(self, in_feats, out_feats):
+        super().__init__()
+        self.fc = nn.Linear(2 * in_feats, out_feats)
+        nn.init.xavier_uniform_(self.fc.weight, gain=nn.init.calculate_gain("relu"))  # dist_sageconv.py:35-41
+
+    # -- the three phases of a layer on one part
+    def local(self, sl, x):
+        """sum-aggregate over the part's own CSR (BipartiteGraph.gather)."""
+        return aggr.SpmmSum.apply(x, sl.indptr, sl.indices, sl.n_out)
+
+    def boundary(self, sl, agg):
+        """partials this part computed for nodes owned by peer p (pull_for_remotes)."""
+        return [aggr.GatherRows.apply(agg, sl.from_ids[p]) if sl.from_ids[p].numel() else None
+                for p in range(sl.n_parts)]
+
+    def merge(self, sl, agg, recv):
+        """add the peers' partials into the owned rows (push_from_remotes / mergeKernel)."""
+        for p in range(sl.n_parts):
+            if recv[p] is not None and sl.to_ids[p].numel():
+                agg = aggr.ScatterAddRows.apply(agg, sl.to_ids[p], recv[p])
+        return agg
+
+    def finish(self, sl, agg, x):
+        """slice_owned_nodes + mean + self_gather + concat + Linear."""
+        neigh = aggr.GatherRows.apply(agg, sl.owned_out_nodes)
+        neigh = neigh / sl.owned_degree.clamp(min=1).to(neigh.dtype).unsqueeze(1)
+        self_h = aggr.GatherRows.apply(x, sl.self_ids_in)
+        return self.fc(torch.cat([self_h, neigh], dim=1))
+
+
+class DistSAGEModel(nn.Module):
+    """models/factory.py:7-56: n_layers DistSageConv, ReLU between, weights replicated on every part."""
+
+    def __init__(self, in_feats, hidden, n_classes, n_layers=3):
+        super().__init__()
+        dims = [in_feats] + [hidden] * (n_layers - 1) + [n_classes]
+        # convs[k] consumes engine layer n_layers-1-k (the deepest hop first)
+        self.convs = nn.ModuleList([DistSageConv(dims[k], dims[k + 1]) for k in range(n_layers)])
+
+    def forward_parts(self, slices, feats):
+        """All parts in ONE process (validation / single GPU): slices[l][g], feats[g] = input
+        features of slices[L-1][g].in_nodes.  Returns per part the logits of its owned seeds."""
+        L = len(slices)
+        parts = sorted(slices[0].keys())
+        x = {g: feats[g] for g in parts}
+        for k, conv in enumerate(self.convs):
+            sl = slices[L - 1 - k]
+            agg = {g: conv.local(sl[g], x[g]) for g in parts}
+            send = {g: conv.boundary(sl[g], agg[g]) for g in parts}
+            for g in parts:
+                agg[g] = conv.merge(sl[g], agg[g], [send[p][g] if p != g else None for p in parts])
+            x = {g: conv.finish(sl[g], agg[g], x[g]) for g in parts}
+            if k + 1 < len(self.convs):
+                x = {g: torch.relu(x[g]) for g in parts}
+        return x
+
+    def forward_rank(self, slices, feat, rank, comm):
+        """One part per process: boundary partials go through `comm.all_to_all` (RCCL)."""
+        L = len(slices)
+        x = feat
+        for k, conv in enumerate(self.convs):
+            sl = slices[L - 1 - k][rank]
+            agg = conv.local(sl, x)
+            send = conv.boundary(sl, agg)
+            recv, tie = comm.all_to_all(send, [sl.to_ids[p].numel() for p in range(sl.n_parts)], agg.shape[1])
+            # `tie` is a zero that depends on the exchange: every rank then runs the reverse
+            # exchange in backward even when it received (or sent) nothing in this layer
+            agg = conv.merge(sl, agg + tie, recv)
+            x = conv.finish(sl, agg, x)
+            if k + 1 < len(self.convs):
+                x = torch.relu(x)
+        return x
+
+
+class _AllToAllRows(torch.autograd.Function):
+    """Differentiable all_to_all_single of row blocks: backward is the reverse exchange."""
+
+    @staticmethod
+    def forward(ctx, comm, send_cat, send_counts, recv_counts):
+        ctx.comm, ctx.send_counts, ctx.recv_counts = comm, send_counts, recv_counts
+        return comm._exchange(send_cat, send_counts, recv_counts)
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, ctx.comm._exchange(g.contiguous(), ctx.recv_counts, ctx.send_counts), None, None
+
+
+class DistComm(object):
+    """Boundary exchange between parts = ranks of a torch.distributed group (backend "nccl" is
+    RCCL on ROCm; "gloo" for CPU tests).  One all_to_all_single per layer."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def _exchange(self, send_cat, send_counts, recv_counts):
+        H = send_cat.shape[1]
+        out = torch.empty((sum(recv_counts), H), dtype=send_cat.dtype, device=send_cat.device)
+        self.dist.all_to_all_single(out, send_cat, output_split_sizes=list(recv_counts),
+                                    input_split_sizes=list(send_counts), group=self.group)
+        return out
+
+    def all_to_all(self, send, recv_counts, H):
+        ref = next((t for t in send if t is not None), None)
+        device = ref.device if ref is not None else torch.device("cuda", torch.cuda.current_device())
+        send_counts = [0 if t is None else t.shape[0] for t in send]
+        parts = [t for t in send if t is not None]
+        send_cat = torch.cat(parts, dim=0) if parts else torch.zeros((0, H), dtype=torch.float32, device=device)
+        if torch.is_grad_enabled() and not send_cat.requires_grad:
+            send_cat = send_cat.detach().requires_grad_()
+        out = _AllToAllRows.apply(self, send_cat, send_counts, list(recv_counts))
+        recv, o = [], 0
+        for c in recv_counts:
+            recv.append(out[o:o + c] if c else None)
+            o += c
+        return recv, out.sum() * 0.0

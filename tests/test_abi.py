@@ -29,6 +29,16 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_abi.SYMBOLS) == names
 
 
+def test_aggregation_symbols_exported():
+    from cslicer import aggr
+    L = _abi.load()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "cslicer_aggr.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(csl_[a-z_0-9]+)\s*\(", src)))
+    assert names == sorted(aggr.SYMBOLS)
+    for n in names:
+        assert hasattr(L, n)
+
+
 def test_abi_version_and_struct_layout():
     L = _abi.load()
     assert L.csl_abi_version() == _abi.ABI_VERSION

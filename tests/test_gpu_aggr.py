@@ -1,0 +1,145 @@
+"""Aggregation kernels (include/cslicer_aggr.h) and the split-parallel GraphSAGE built on them,
+against plain torch fp32 references.  The reference's Python consumer needs DGL (absent here,
+ModuleNotFoundError) and ships no goldens: these results are pinned by analytic torch references
+only ("parity unpinned" by the reference).  Tolerance: 1e-5 (north_star: aggregation outputs
+within 1e-5 fp32)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from cslicer import _abi, aggr, splitgnn
+    _abi.load()
+    return _abi, aggr, splitgnn
+
+
+def _rand_csr(n_rows, n_src, max_deg, rng):
+    deg = rng.integers(0, max_deg + 1, size=n_rows)
+    indptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    indices = rng.integers(0, n_src, size=int(indptr[-1])).astype(np.int64)
+    return indptr, indices
+
+
+@pytest.mark.parametrize("H", [1, 3, 4, 32, 100, 128, 256, 300])
+def test_spmm_sum_forward_backward(mods, H):
+    _, aggr, _ = mods
+    rng = np.random.default_rng(H)
+    n_rows, n_src = 777, 500
+    indptr, indices = _rand_csr(n_rows, n_src, 15, rng)
+    x = torch.randn(n_src, H, dtype=torch.float32)
+    ip, ix = torch.from_numpy(indptr), torch.from_numpy(indices)
+    # torch fp32 reference: dense accumulation in edge order
+    ref = torch.zeros(n_rows, H)
+    rows = torch.repeat_interleave(torch.arange(n_rows), torch.from_numpy(np.diff(indptr)))
+    ref.index_add_(0, rows, x[ix])
+    xg = x.cuda().requires_grad_()
+    out = aggr.SpmmSum.apply(xg, ip.cuda(), ix.cuda(), n_rows)
+    torch.testing.assert_close(out.cpu(), ref, **TOL)
+    g = torch.randn(n_rows, H)
+    out.backward(g.cuda())
+    gref = torch.zeros(n_src, H)
+    gref.index_add_(0, ix, g[rows])
+    torch.testing.assert_close(xg.grad.cpu(), gref, rtol=1e-5, atol=2e-5)
+    # row subset (boundary rows first)
+    sel = torch.from_numpy(rng.choice(n_rows, size=100, replace=False).astype(np.int64))
+    part = aggr.spmm_sum(ip.cuda(), ix.cuda(), x.cuda(), n_rows, rows=sel.cuda())
+    torch.testing.assert_close(part.cpu()[sel], ref[sel], **TOL)
+    mask = torch.ones(n_rows, dtype=torch.bool)
+    mask[sel] = False
+    assert float(part.cpu()[mask].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("H", [5, 64, 128])
+def test_gather_scatter_div_rows(mods, H):
+    _, aggr, _ = mods
+    rng = np.random.default_rng(7 + H)
+    src = torch.randn(400, H)
+    idx = torch.from_numpy(rng.choice(400, size=150, replace=False).astype(np.int64))
+    idx_m = idx.clone()
+    idx_m[::7] = -1
+    got = aggr.gather_rows(src.cuda(), idx_m.cuda()).cpu()
+    ref = src[idx_m.clamp(min=0)] * (idx_m >= 0).unsqueeze(1)
+    torch.testing.assert_close(got, ref, rtol=0, atol=0)
+    dst = torch.randn(400, H)
+    add = torch.randn(150, H)
+    got = aggr.scatter_add_rows_(dst.clone().cuda(), idx.cuda(), add.cuda()).cpu()
+    ref = dst.clone()
+    ref[idx] += add
+    torch.testing.assert_close(got, ref, **TOL)
+    deg = torch.from_numpy(rng.integers(0, 20, size=400).astype(np.int64))
+    got = aggr.div_rows_(dst.clone().cuda(), deg.cuda()).cpu()
+    torch.testing.assert_close(got, dst / deg.clamp(min=1).unsqueeze(1), **TOL)
+    # autograd of the wrappers
+    s = src.clone().cuda().requires_grad_()
+    aggr.GatherRows.apply(s, idx.cuda()).sum().backward()
+    gref = torch.zeros(400, H)
+    gref[idx] = 1.0
+    torch.testing.assert_close(s.grad.cpu(), gref, rtol=0, atol=0)
+
+
+def _dense_reference(model, indptr, indices, trav, feats, P):
+    """Unsplit torch fp32 GraphSAGE on the same sampled computation graph (CPU)."""
+    L = len(trav["nbr_counts"])
+    h = feats.clone()
+    for k, conv in enumerate(model.convs):
+        l = L - 1 - k
+        fr = trav["frontier"][l]
+        counts, flat = trav["nbr_counts"][l], trav["nbr_flat"][l]
+        new = torch.zeros(h.shape[0], conv.fc.out_features)
+        pos = 0
+        for i, nd1 in enumerate(fr):
+            nb = flat[pos + 1:pos + counts[i]]
+            pos += counts[i]
+            nb = nb[nb != nd1]
+            neigh = h[nb].sum(0) / max(len(nb), 1) if len(nb) else torch.zeros(h.shape[1])
+            new[nd1] = conv.fc(torch.cat([h[nd1], neigh]))
+        h = torch.relu(new) if k + 1 < len(model.convs) else new
+    return h
+
+
+@pytest.mark.parametrize("P,fan", [(4, (10, 10, 10)), (2, (15, 10, 5)), (1, (5, 5))])
+def test_split_parallel_sage_matches_dense_reference(mods, P, fan):
+    abi, aggr, sg = mods
+    from cslicer import l0
+    from oracle import oracle as orc
+    torch.manual_seed(0)
+    n, F0, hidden, classes, B = 3000, 20, 16, 7, 64
+    indptr, indices = l0.synth_graph(n, 12.0, seed=5)
+    seeds = np.random.default_rng(2).permutation(n)[:B]
+    eng = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, mode=abi.MODE_GRAPH)
+    eng.submit_seeds([seeds])
+    slices = sg.slices_of(eng)
+    L = len(fan)
+    feats = torch.randn(n, F0)
+    model = sg.DistSAGEModel(F0, hidden, classes, n_layers=L)
+    # each part reads only the features of nodes it owns
+    x = {g: feats[slices[L - 1][g].in_nodes.cpu()].cuda().requires_grad_() for g in range(P)}
+    for g in range(P):
+        assert bool((slices[L - 1][g].in_nodes % P == g).all())
+    gm = sg.DistSAGEModel(F0, hidden, classes, n_layers=L).cuda()
+    gm.load_state_dict(model.state_dict())
+    out = gm.forward_parts(slices, x)
+    trav = orc.Oracle(indptr, indices, n_parts=P, fanouts=fan).sample(seeds)
+    fin = feats.clone().requires_grad_()
+    ref = _dense_reference(model, indptr, indices, trav, fin, P)
+    for g in range(P):
+        own = seeds[seeds % P == g]
+        torch.testing.assert_close(out[g].detach().cpu(), ref[own].detach(), **TOL)
+    # backward: same loss on both sides
+    w = torch.randn(n, classes)
+    loss_ref = (ref[seeds] * w[seeds]).sum()
+    loss_ref.backward()
+    loss = sum((out[g] * w[seeds[seeds % P == g]].cuda()).sum() for g in range(P))
+    loss.backward()
+    for (na, pa), (nb, pb) in zip(gm.named_parameters(), model.named_parameters()):
+        torch.testing.assert_close(pa.grad.cpu(), pb.grad, rtol=1e-4, atol=1e-5, msg="grad " + na)
+    for g in range(P):
+        ids = slices[L - 1][g].in_nodes.cpu()
+        torch.testing.assert_close(x[g].grad.cpu(), fin.grad[ids], rtol=1e-4, atol=1e-5)
+    eng.close()
