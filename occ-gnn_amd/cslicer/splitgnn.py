@@ -187,15 +187,23 @@ class DistComm(object):
     """Boundary exchange between parts = ranks of a torch.distributed group (backend "nccl" is
     RCCL on ROCm; "gloo" for CPU tests).  One all_to_all_single per layer."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, device=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
+        self.device = device if device is not None else (
+            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
     def _exchange(self, send_cat, send_counts, recv_counts):
         H = send_cat.shape[1]
+        if self.dist.get_backend(self.group) == "gloo" and send_cat.is_cuda:
+            # rehearsal backend (several ranks sharing one GPU): stage through host memory
+            out = torch.empty((sum(recv_counts), H), dtype=send_cat.dtype)
+            self.dist.all_to_all_single(out, send_cat.cpu(), output_split_sizes=list(recv_counts),
+                                        input_split_sizes=list(send_counts), group=self.group)
+            return out.to(send_cat.device)
         out = torch.empty((sum(recv_counts), H), dtype=send_cat.dtype, device=send_cat.device)
         self.dist.all_to_all_single(out, send_cat, output_split_sizes=list(recv_counts),
                                     input_split_sizes=list(send_counts), group=self.group)
@@ -203,7 +211,7 @@ class DistComm(object):
 
     def all_to_all(self, send, recv_counts, H):
         ref = next((t for t in send if t is not None), None)
-        device = ref.device if ref is not None else torch.device("cuda", torch.cuda.current_device())
+        device = ref.device if ref is not None else self.device
         send_counts = [0 if t is None else t.shape[0] for t in send]
         parts = [t for t in send if t is not None]
         send_cat = torch.cat(parts, dim=0) if parts else torch.zeros((0, H), dtype=torch.float32, device=device)

@@ -1,0 +1,121 @@
+"""End-to-end split-parallel GraphSAGE training step on the slices: the counterpart of the
+reference's python/train.py:19-106 (Adam, cross-entropy, 3-layer DistSAGEModel), one process per
+GPU over torch.distributed (RCCL) instead of one process driving 4 GPUs with
+torch.nn.parallel.replicate/gather.
+
+Per rank g (= part g): an engine in CSL_MODE_GRAPH slices S minibatches per round (every rank
+slices the same minibatches, deterministically; nothing about topology is communicated), the rank
+keeps the features and labels of the nodes it owns, runs DistSAGEModel.forward_rank on its slice,
+cross-entropy on the seeds it owns, backward (boundary gradients travel the reverse all-to-all),
+all-reduce of the replicated weights' gradients, Adam.
+
+The print keys of train.py:101-103 are kept (`avg forward time`, `batch slice time`,
+`cache refresh time`; there is no feature cache here: features are resident in HBM, so the last
+one is reported as 0).
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import _abi, splitgnn
+
+
+class Trainer(object):
+    def __init__(self, indptr, indices, features, labels, n_classes, rank=0, world=1, fanouts=(15, 10, 5),
+                 batch=1024, streams=8, hidden=256, lr=1e-3, device=0, dist=None, seed=0):
+        """features: float32 [N, F] (host, the rank keeps only the rows it owns); labels int64 [N]."""
+        self.rank, self.world, self.dist = rank, world, dist
+        self.P = world
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        N = indptr.shape[0] - 1
+        self.N, self.B, self.S, self.L = N, batch, streams, len(fanouts)
+        self.eng = _abi.Engine(indptr, indices, n_parts=self.P, fanouts=fanouts, max_batch=batch,
+                               n_streams=streams, n_slots=2, device=device, mode=_abi.MODE_GRAPH)
+        own = np.arange(rank, N, self.P)
+        self.feat = torch.from_numpy(np.ascontiguousarray(features[own])).to(self.dev)   # row v // P of owner v % P
+        self.labels = torch.from_numpy(np.ascontiguousarray(labels[own])).to(self.dev)
+        torch.manual_seed(seed)      # identical replicated weights on every rank
+        self.model = splitgnn.DistSAGEModel(features.shape[1], hidden, n_classes, n_layers=self.L).to(self.dev)
+        self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
+        self.comm = splitgnn.DistComm(device=self.dev) if world > 1 else None
+        self.t_forward = self.t_slice = 0.0
+        self.steps_done = 0
+
+    def set_nodes(self, nodes):
+        self.eng.set_nodes(nodes)
+        self.n_batches = (len(nodes) + self.B - 1) // self.B
+
+    def _step(self, stream, slot):
+        t0 = time.perf_counter()
+        slices = splitgnn.slices_of(self.eng, stream, slot, parts=[self.rank], device=self.dev)
+        self.t_slice += time.perf_counter() - t0
+        deep = slices[self.L - 1][self.rank]
+        x = self.feat[deep.in_nodes // self.P]          # gather of owned input features
+        t1 = time.perf_counter()
+        if self.world > 1:
+            logits = self.model.forward_rank(slices, x, self.rank, self.comm)
+        else:
+            logits = self.model.forward_parts(slices, {0: x})[0]
+        top = slices[0][self.rank]
+        seeds = top.out_nodes[top.owned_out_nodes]        # the seeds this rank owns, frontier order
+        y = self.labels[seeds // self.P]
+        # mean over the WHOLE minibatch: sum of local losses / global seed count
+        n_seeds = int(self.eng.meta(stream, slot).n_seeds)
+        loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / max(n_seeds, 1)
+        self.t_forward += time.perf_counter() - t1
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.world > 1:
+            flat = torch.cat([p.grad.reshape(-1) for p in self.model.parameters()])
+            self.dist.all_reduce(flat)                    # replicated weights: sum of per-rank gradients
+            o = 0
+            for p in self.model.parameters():
+                n = p.numel()
+                p.grad.copy_(flat[o:o + n].view_as(p))
+                o += n
+        self.opt.step()
+        self.steps_done += 1
+        return loss.detach()
+
+    def run(self, n_steps, first_batch=0):
+        """n_steps minibatches, S per engine round; the next round is sliced while this one trains."""
+        losses = []
+        rounds = (n_steps + self.S - 1) // self.S
+        per_epoch = max(1, self.n_batches // self.S)
+
+        def submit(r):
+            torch.cuda.current_stream().synchronize()     # the slot's previous consumer has finished
+            first = ((first_batch // self.S + r) % per_epoch) * self.S
+            self.eng.submit_round(first, self.B, self.S, slot=r & 1)
+
+        submit(0)
+        done = 0
+        for r in range(rounds):
+            if r + 1 < rounds:
+                submit(r + 1)
+            for s in range(self.S):
+                if done >= n_steps:
+                    break
+                losses.append(self._step(s, r & 1))
+                done += 1
+        torch.cuda.synchronize()
+        return [float(x) for x in losses]
+
+    def report(self):
+        n = max(self.steps_done, 1)
+        # keys of python/train.py:101-103 (parsed by experiments/exp6/occ.py:21-23)
+        return ("avg forward time: %.6f sec\nbatch slice time: %.6f sec\ncache refresh time: %.6f sec"
+                % (self.t_forward / n, self.t_slice / n, 0.0))
+
+    def close(self):
+        self.eng.close()
+
+
+def synthetic_node_data(num_nodes, feat_dim, n_classes, seed=0):
+    """features f32 U[0,1) and random labels (datasets are not available offline)."""
+    rng = np.random.default_rng(seed)
+    feats = rng.random((num_nodes, feat_dim), dtype=np.float32)
+    labels = rng.integers(0, n_classes, size=num_nodes).astype(np.int64)
+    return feats, labels
