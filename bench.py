@@ -49,6 +49,14 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
+    ap.add_argument("--e2e-steps", type=int, default=64,
+                    help="end-to-end training minibatches for the secondary iters/s figure (0 = skip)")
+    ap.add_argument("--e2e-multi", action="store_true",
+                    help="also run the end-to-end leg when WORLD_SIZE > 1 (boundary all-to-all over RCCL); off by "
+                         "default so the slicer scaling runs never depend on it")
+    ap.add_argument("--e2e-hidden", type=int, default=256)
+    ap.add_argument("--e2e-feat", type=int, default=100)
+    ap.add_argument("--e2e-classes", type=int, default=47)
     return ap.parse_args()
 
 
@@ -232,6 +240,41 @@ def main():
         },
     }
 
+    # ---- end-to-end minibatch rate: slice + feature gather + forward/backward + Adam, one part per GPU
+    if args.e2e_steps > 0 and (world == 1 or args.e2e_multi):
+        eng.close()
+        eng = None
+        from cslicer.train import Trainer, synthetic_node_data
+        feats, labels = synthetic_node_data(N, args.e2e_feat, args.e2e_classes, seed=0)
+        tr = Trainer(indptr, indices, feats, labels, args.e2e_classes, rank=rank, world=world, fanouts=fan,
+                     batch=B, streams=8, hidden=args.e2e_hidden, device=device, dist=dist)
+        del feats
+        tr.set_nodes(perm)
+        tr.run(16)                       # warm-up (allocator, rng window, GEMM heuristics)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.run(args.e2e_steps, first_batch=16)
+        torch.cuda.synchronize()
+        barrier()
+        t_e2e = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)
+        out["e2e"] = {
+            "iters_per_sec": args.e2e_steps / t_e2e, "ms_per_iter": 1e3 * t_e2e / args.e2e_steps,
+            "steps": args.e2e_steps,
+            "config": "split-parallel GraphSAGE fanout %s, batch %d (global), %d part(s) = %d GPU(s), features %d, "
+                      "hidden %d, classes %d, fp32, Adam; slice+gather+fwd+bwd+step" % (
+                          "/".join(map(str, fan)), B, world, world, args.e2e_feat, args.e2e_hidden, args.e2e_classes),
+            "scaling": "strong",
+        }
+        tr.close()
+        eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2,
+                          device=device) if (rank == 0 and not args.no_kernel_timing) else None
+        if eng is not None:
+            eng.set_nodes(perm)
+            for w in range(args.warmup):
+                run_round(w)
+            eng.sync()
+
     if rank == 0:
         # ---- per-kernel HIP-event timing pass (engine's own stream) for the roofline
         if not args.no_kernel_timing:
@@ -307,7 +350,8 @@ def main():
                 "single_thread": {"value": e1 / sec1, "iters_per_sec": 2 / sec1, "sample": "2 minibatches"},
             }
         print(json.dumps(out))
-    eng.close()
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
