@@ -29,9 +29,11 @@ extern "C" {
 int csl_spmm_sum_f32(const int64_t* indptr, const int64_t* indices, const int64_t* rows, int64_t n_rows,
                      const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, void* stream);
 
-/* grad_x[indices[e], :] += grad_out[r, :] for every edge e of row r (fp32 atomics). */
-int csl_spmm_sum_bwd_f32(const int64_t* indptr, const int64_t* indices, int64_t n_rows, const float* grad_out,
-                         int64_t ldg, float* grad_x, int64_t ldx, int32_t H, void* stream);
+/* grad_x[indices[e], :] += grad_out[q, :] for every edge e of row = rows ? rows[r] : r,
+ * r in [0, n_rows); q = compact ? r : row (compact: grad_out holds only the listed rows). fp32 atomics. */
+int csl_spmm_sum_bwd_f32(const int64_t* indptr, const int64_t* indices, const int64_t* rows, int64_t n_rows,
+                         const float* grad_out, int64_t ldg, int32_t compact, float* grad_x, int64_t ldx, int32_t H,
+                         void* stream);
 
 /* dst[k, :] = idx[k] >= 0 ? src[idx[k], :] : 0 */
 int csl_gather_rows_f32(const float* src, int64_t lds, const int64_t* idx, int64_t n, float* dst, int64_t ldd,

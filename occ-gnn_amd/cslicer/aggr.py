@@ -22,7 +22,7 @@ def _lib():
     if not _ready:
         vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
         L.csl_spmm_sum_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, i32, vp]
-        L.csl_spmm_sum_bwd_f32.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp]
+        L.csl_spmm_sum_bwd_f32.argtypes = [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp]
         L.csl_gather_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_scatter_add_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_div_rows_f32.argtypes = [vp, i64, vp, i64, i32, vp]
@@ -70,11 +70,16 @@ def spmm_sum(indptr, indices, x, n_rows, rows=None, out=None):
     return out
 
 
-def spmm_sum_bwd(indptr, indices, grad_out, n_src):
+def spmm_sum_bwd(indptr, indices, grad_out, n_src, rows=None, compact=False, out=None):
+    """grad wrt the sources of spmm_sum.  rows: only these output rows contribute; compact: grad_out
+    holds just those rows (k-th row of grad_out belongs to rows[k]).  Accumulates into `out` if given."""
     g = _f32(grad_out)
-    gx = torch.zeros((n_src, g.shape[1]), dtype=torch.float32, device=g.device)
-    _chk(_lib().csl_spmm_sum_bwd_f32(_p(_i64(indptr)), _p(_i64(indices)), g.shape[0], _p(g), g.stride(0), _p(gx),
-                                     gx.stride(0), g.shape[1], _stream()), "csl_spmm_sum_bwd_f32")
+    gx = out if out is not None else torch.zeros((n_src, g.shape[1]), dtype=torch.float32, device=g.device)
+    n = g.shape[0] if rows is None else rows.numel()
+    _chk(_lib().csl_spmm_sum_bwd_f32(_p(_i64(indptr)), _p(_i64(indices)),
+                                     _p(rows) if rows is not None else C.c_void_p(0), n, _p(g), g.stride(0),
+                                     1 if compact else 0, _p(gx), gx.stride(0), g.shape[1], _stream()),
+         "csl_spmm_sum_bwd_f32")
     return gx
 
 

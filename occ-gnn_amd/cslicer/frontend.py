@@ -134,7 +134,7 @@ class cslicer(object):
 
     def __init__(self, name, queue_size, no_worker_threads, number_of_epochs, minibatch_size,
                  data_root=None, fanout=(10, 10, 10), n_parts=4, device=0, seed=5489,
-                 shuffle=True):
+                 shuffle=True, partition="mod"):
         root = data_root or os.environ.get("CSLICER_DATA_ROOT", DEFAULT_DATA_ROOT)
         self.name = os.path.join(root, name)
         if not os.path.isdir(self.name):
@@ -148,9 +148,19 @@ class cslicer(object):
         self.num_nodes = int(meta["num_nodes"])
         self._shuffle = bool(shuffle)
         S = max(1, self.no_worker_threads)
+        # the reference loads partition_map_opt.bin (dataset.cpp:59-67) but slices by v % 4
+        # (pyfrontend.cpp:57); partition="file" uses the map (METIS output of python/utils/metis.py)
+        workload = None
+        if partition == "file":
+            workload = np.fromfile(os.path.join(self.name, "partition_map_opt.bin"), dtype=np.int32,
+                                   count=self.num_nodes)
+            if workload.shape[0] != self.num_nodes:
+                raise ValueError("partition_map_opt.bin is shorter than num_nodes")
+        elif partition != "mod":
+            raise ValueError("partition must be 'mod' or 'file'")
         self._eng = _abi.Engine(indptr, indices, n_parts=n_parts, fanouts=tuple(fanout),
                                 max_batch=self.minibatch_size, n_streams=S, n_slots=2,
-                                device=device, rng_seed=seed)
+                                device=device, rng_seed=seed, workload=workload)
         self._S = S
         self._training_nodes = np.arange(self.num_nodes, dtype=np.int64)  # WorkerPool.cpp:12-16
         self._batches_per_epoch = (self.num_nodes - 1) // self.minibatch_size + 1

@@ -152,12 +152,19 @@ class DistSAGEModel(nn.Module):
                 x = {g: torch.relu(x[g]) for g in parts}
         return x
 
-    def forward_rank(self, slices, feat, rank, comm):
-        """One part per process: boundary partials go through `comm.all_to_all` (RCCL)."""
+    def forward_rank(self, slices, feat, rank, comm, overlap=False):
+        """One part per process: boundary partials go through `comm.all_to_all` (RCCL).
+        overlap=True runs each layer's exchange on a side stream while the rows that stay on
+        this GPU are aggregated (`_OverlappedAggregate`); same numbers, different schedule."""
         L = len(slices)
         x = feat
         for k, conv in enumerate(self.convs):
             sl = slices[L - 1 - k][rank]
+            if overlap:
+                x = conv.finish(sl, _OverlappedAggregate.apply(x, sl, comm), x)
+                if k + 1 < len(self.convs):
+                    x = torch.relu(x)
+                continue
             agg = conv.local(sl, x)
             send = conv.boundary(sl, agg)
             recv, tie = comm.all_to_all(send, [sl.to_ids[p].numel() for p in range(sl.n_parts)], agg.shape[1])
@@ -168,6 +175,76 @@ class DistSAGEModel(nn.Module):
             if k + 1 < len(self.convs):
                 x = torch.relu(x)
         return x
+
+
+class _OverlappedAggregate(torch.autograd.Function):
+    """local sum-aggregate + boundary exchange + merge of ONE layer on ONE rank, with the
+    all-to-all on the communicator's side stream while the rows that never leave the GPU are
+    still being aggregated.
+
+    forward   rows owned by peers first -> send buffers -> [side stream: all-to-all]
+              || rows owned by this part -> wait -> add received partials into the owned rows
+    backward  grads of received partials -> [side stream: reverse all-to-all]
+              || backward of the owned rows -> wait -> backward of the peer-owned rows
+    """
+
+    @staticmethod
+    def forward(ctx, x, sl, comm):
+        g, P = sl.part, sl.n_parts
+        peers = [p for p in range(P) if p != g]
+        remote_rows = torch.cat([sl.from_ids[p] for p in peers]) if peers else sl.from_ids[g]
+        send_counts = [0 if p == g else sl.from_ids[p].numel() for p in range(P)]
+        recv_counts = [0 if p == g else sl.to_ids[p].numel() for p in range(P)]
+        H = x.shape[1]
+        main = torch.cuda.current_stream()
+        side = comm.side_stream()
+        agg = torch.empty((sl.n_out, H), dtype=torch.float32, device=x.device)
+        aggr.spmm_sum(sl.indptr, sl.indices, x, sl.n_out, rows=remote_rows, out=agg)
+        send_cat = aggr.gather_rows(agg, remote_rows)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            recv_cat = comm._exchange(send_cat, send_counts, recv_counts)
+            done = torch.cuda.Event()
+            done.record(side)
+        send_cat.record_stream(side)
+        aggr.spmm_sum(sl.indptr, sl.indices, x, sl.n_out, rows=sl.owned_out_nodes, out=agg)   # overlaps
+        main.wait_event(done)
+        recv_cat.record_stream(main)
+        o = 0
+        for p in range(P):                 # one peer at a time: rows repeat across peers, never inside one
+            c = recv_counts[p]
+            if c:
+                aggr.scatter_add_rows_(agg, sl.to_ids[p], recv_cat[o:o + c])
+            o += c
+        ctx.sl, ctx.comm, ctx.n_src = sl, comm, x.shape[0]
+        ctx.remote_rows, ctx.send_counts, ctx.recv_counts = remote_rows, send_counts, recv_counts
+        return agg
+
+    @staticmethod
+    def backward(ctx, G):
+        sl, comm = ctx.sl, ctx.comm
+        G = G.contiguous()
+        P = sl.n_parts
+        to_cat = torch.cat([sl.to_ids[p] for p in range(P) if p != sl.part]) if P > 1 else sl.to_ids[0]
+        main = torch.cuda.current_stream()
+        side = comm.side_stream()
+        g_recv = aggr.gather_rows(G, to_cat)          # d loss / d (partials received from each peer)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            back = comm._exchange(g_recv, ctx.recv_counts, ctx.send_counts)   # grads of what this rank sent
+            done = torch.cuda.Event()
+            done.record(side)
+        g_recv.record_stream(side)
+        gx = aggr.spmm_sum_bwd(sl.indptr, sl.indices, G, ctx.n_src, rows=sl.owned_out_nodes)   # overlaps
+        main.wait_event(done)
+        back.record_stream(main)
+        g_remote = aggr.gather_rows(G, ctx.remote_rows) + back
+        aggr.spmm_sum_bwd(sl.indptr, sl.indices, g_remote, ctx.n_src, rows=ctx.remote_rows, compact=True, out=gx)
+        return gx, None, None
 
 
 class _AllToAllRows(torch.autograd.Function):
@@ -195,6 +272,12 @@ class DistComm(object):
             torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self._side = None
+
+    def side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def _exchange(self, send_cat, send_counts, recv_counts):
         H = send_cat.shape[1]

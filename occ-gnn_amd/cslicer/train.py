@@ -23,7 +23,7 @@ from . import _abi, splitgnn
 
 class Trainer(object):
     def __init__(self, indptr, indices, features, labels, n_classes, rank=0, world=1, fanouts=(15, 10, 5),
-                 batch=1024, streams=8, hidden=256, lr=1e-3, device=0, dist=None, seed=0):
+                 batch=1024, streams=8, hidden=256, lr=1e-3, device=0, dist=None, seed=0, overlap=False):
         """features: float32 [N, F] (host, the rank keeps only the rows it owns); labels int64 [N]."""
         self.rank, self.world, self.dist = rank, world, dist
         self.P = world
@@ -40,6 +40,7 @@ class Trainer(object):
         self.model = splitgnn.DistSAGEModel(features.shape[1], hidden, n_classes, n_layers=self.L).to(self.dev)
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
         self.comm = splitgnn.DistComm(device=self.dev) if world > 1 else None
+        self.overlap = overlap
         self.t_forward = self.t_slice = 0.0
         self.steps_done = 0
 
@@ -55,7 +56,7 @@ class Trainer(object):
         x = self.feat[deep.in_nodes // self.P]          # gather of owned input features
         t1 = time.perf_counter()
         if self.world > 1:
-            logits = self.model.forward_rank(slices, x, self.rank, self.comm)
+            logits = self.model.forward_rank(slices, x, self.rank, self.comm, overlap=self.overlap)
         else:
             logits = self.model.forward_parts(slices, {0: x})[0]
         top = slices[0][self.rank]

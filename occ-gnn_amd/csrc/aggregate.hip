@@ -97,15 +97,18 @@ __global__ __launch_bounds__(BLK) void k_spmm_sum(const long long* __restrict__ 
 // the row's gradient into each source row, 64 consecutive floats per atomic instruction
 // (the shape the chip's memory-side float atomics run fastest at)
 __global__ __launch_bounds__(BLK) void k_spmm_sum_bwd(const long long* __restrict__ indptr,
-                                                      const long long* __restrict__ indices, long long n_rows,
-                                                      const float* __restrict__ g, long long ldg,
+                                                      const long long* __restrict__ indices,
+                                                      const long long* __restrict__ rows, long long n_rows,
+                                                      const float* __restrict__ g, long long ldg, int compact,
                                                       float* __restrict__ gx, long long ldx, int H) {
   const int lane = threadIdx.x & 63;
   const long long r = (long long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
   if (r >= n_rows) return;
-  const long long e0 = indptr[r], e1 = indptr[r + 1];
+  const long long row = rows ? rows[r] : r;
+  const long long q = compact ? r : row;
+  const long long e0 = indptr[row], e1 = indptr[row + 1];
   for (int c = lane; c < H; c += 64) {
-    const float v = g[r * ldg + c];
+    const float v = g[q * ldg + c];
     for (long long e = e0; e < e1; e++) atomicAdd(gx + indices[e] * ldx + c, v);
   }
 }
@@ -213,14 +216,15 @@ int csl_spmm_sum_f32(const int64_t* indptr, const int64_t* indices, const int64_
   return done();
 }
 
-int csl_spmm_sum_bwd_f32(const int64_t* indptr, const int64_t* indices, int64_t n_rows, const float* grad_out,
-                         int64_t ldg, float* grad_x, int64_t ldx, int32_t H, void* stream) {
+int csl_spmm_sum_bwd_f32(const int64_t* indptr, const int64_t* indices, const int64_t* rows, int64_t n_rows,
+                         const float* grad_out, int64_t ldg, int32_t compact, float* grad_x, int64_t ldx, int32_t H,
+                         void* stream) {
   if (n_rows < 0 || H < 1 || !indptr || !grad_out || !grad_x) return CSL_E_INVALID;
   if (n_rows == 0) return CSL_OK;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_spmm_sum_bwd, dim3((unsigned)((n_rows + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st,
-                     (const long long*)indptr, (const long long*)indices, (long long)n_rows, grad_out, (long long)ldg,
-                     grad_x, (long long)ldx, (int)H);
+                     (const long long*)indptr, (const long long*)indices, (const long long*)rows, (long long)n_rows,
+                     grad_out, (long long)ldg, (int)compact, grad_x, (long long)ldx, (int)H);
   return done();
 }
 

@@ -180,7 +180,7 @@ class CSlicer {
  public:
   CSlicer(const std::string& name, int queue_size, int no_worker_threads, int number_of_epochs, int minibatch_size,
           const std::string& data_root, const std::vector<int>& fanout, int n_parts, int device, unsigned seed,
-          bool shuffle)
+          bool shuffle, const std::string& partition)
       : queue_size_(queue_size),
         workers_(std::max(1, no_worker_threads)),
         epochs_(number_of_epochs),
@@ -207,7 +207,21 @@ class CSlicer {
     c.num_edges = dataset_->num_edges;
     c.indptr = reinterpret_cast<const int64_t*>(dataset_->indptr.data());
     c.indices = reinterpret_cast<const int64_t*>(dataset_->indices.data());
-    c.workload = nullptr;  // v % n_parts, pyfrontend.cpp:57
+    // the reference loads partition_map_opt.bin (dataset.cpp:59-67) but slices by v % 4
+    // (pyfrontend.cpp:57); partition="file" uses the map (METIS output of python/utils/metis.py)
+    std::vector<int> part_map;
+    c.workload = nullptr;
+    if (partition == "file") {
+      part_map.resize(num_nodes_);
+      std::ifstream f(name_ + "/partition_map_opt.bin", std::ios::binary);
+      if (!f) throw std::runtime_error("cslicer: cannot open " + name_ + "/partition_map_opt.bin");
+      f.read(reinterpret_cast<char*>(part_map.data()), (std::streamsize)(part_map.size() * sizeof(int)));
+      if ((size_t)f.gcount() != part_map.size() * sizeof(int))
+        throw std::runtime_error("cslicer: partition_map_opt.bin is shorter than num_nodes");
+      c.workload = part_map.data();
+    } else if (partition != "mod") {
+      throw std::runtime_error("cslicer: partition must be 'mod' or 'file'");
+    }
     c.n_parts = n_parts;
     c.n_layers = n_layers_;
     for (int l = 0; l < n_layers_; l++) c.fanout[l] = fanout[l];
@@ -342,11 +356,11 @@ PYBIND11_MODULE(cslicer, m) {
       .def_readwrite("gpu_id", &PyBipartite::gpu_id);
   py::class_<CSlicer>(m, "cslicer")
       .def(py::init<const std::string&, int, int, int, int, const std::string&, const std::vector<int>&, int, int,
-                    unsigned, bool>(),
+                    unsigned, bool, const std::string&>(),
            py::arg("name"), py::arg("queue_size"), py::arg("no_worker_threads"), py::arg("number_of_epochs"),
            py::arg("minibatch_size"), py::arg("data_root") = std::string(),
            py::arg("fanout") = std::vector<int>{10, 10, 10}, py::arg("n_parts") = 4, py::arg("device") = 0,
-           py::arg("seed") = 5489u, py::arg("shuffle") = true)
+           py::arg("seed") = 5489u, py::arg("shuffle") = true, py::arg("partition") = std::string("mod"))
       .def("getSample", &CSlicer::getSample, py::return_value_policy::take_ownership,
            py::call_guard<py::gil_scoped_release>())
       .def("getNoSamples", &CSlicer::expected_number_of_samples);

@@ -402,3 +402,27 @@ def test_eight_parts_workload_table_large_fanout(abi, orc):
         want = orc.Oracle(indptr, indices, n_parts=8, fanouts=(25, 3), workload=wl).sample(perm[s * 300:(s + 1) * 300])
         assert_same_sample(e.sample_dict(s), want, what="8 parts stream %d" % s)
     e.close()
+
+
+def test_frontends_use_partition_map_file(orc, tmp_path, monkeypatch):
+    """partition="file": slices follow partition_map_opt.bin (the METIS map the reference loads but
+    ignores, dataset.cpp:59-67 / pyfrontend.cpp:57) in both host frontends."""
+    import cslicer as mod
+    from conftest import load_native_module
+    from cslicer import l0
+    n = 2500
+    indptr, indices = l0.synth_graph(n, 16.0, seed=12)
+    pmap = np.random.default_rng(4).integers(0, 4, size=n).astype(np.int32)
+    l0.write_l0(str(tmp_path / "pm"), indptr, indices, partition=pmap)
+    want = orc.Oracle(indptr, indices, workload=pmap).sample(np.arange(200))
+    for ctor in (lambda: mod.cslicer("pm", 4, 1, 1, 200, data_root=str(tmp_path), shuffle=False, partition="file"),
+                 lambda: load_native_module().cslicer("pm", 4, 1, 1, 200, data_root=str(tmp_path), shuffle=False,
+                                                      partition="file")):
+        csl = ctor()
+        s = csl.getSample()
+        for l in range(3):
+            for g in range(4):
+                assert s.layers[l][g].in_nodes == want["layers"][l][g]["in_nodes"].tolist()
+                assert s.layers[l][g].self_ids_in == want["layers"][l][g]["self_ids_in"].tolist()
+                assert s.layers[l][g].from_ids[g] == want["layers"][l][g]["from_ids"][g].tolist()
+        del csl

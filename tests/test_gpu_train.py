@@ -45,7 +45,7 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, q):
+def _rank_main(rank, world, port, q, overlap=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "occ-gnn_amd"))
@@ -58,7 +58,7 @@ def _rank_main(rank, world, port, q):
     from test_gpu_train import _task
     indptr, indices, feats, labels, perm = _task()
     t = Trainer(indptr, indices, feats, labels, 5, rank=rank, world=world, fanouts=(10, 5), batch=128, streams=2,
-                hidden=16, lr=1e-2, dist=dist)
+                hidden=16, lr=1e-2, dist=dist, overlap=overlap)
     t.set_nodes(perm)
     losses = t.run(4)
     tl = torch.tensor(losses, dtype=torch.float64)
@@ -70,14 +70,15 @@ def _rank_main(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_single_process_two_parts():
+@pytest.mark.parametrize("overlap", [False, True], ids=["sequential", "side-stream-overlap"])
+def test_two_ranks_match_single_process_two_parts(overlap):
     import torch.multiprocessing as mp
     from cslicer import _abi, splitgnn
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
