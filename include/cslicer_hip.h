@@ -192,9 +192,10 @@ int csl_frontier_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t
 int64_t csl_copy_frontier(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int64_t* dst,
                           int64_t cap);
 
-/* HIP stream the engine launches on (a hipStream_t), for callers that order
- * their own work after a round */
-int csl_hip_stream(csl_engine* e, void** out);
+/* HIP stream (a hipStream_t) the rounds of result slot `slot` are launched on, for callers
+ * that order their own work after a round.  With >= 2 slots, rounds alternate between two
+ * streams (and two scratch sets) so that consecutive rounds overlap on the GPU. */
+int csl_hip_stream(csl_engine* e, int32_t slot, void** out);
 
 /* time the dominant kernels of the last rounds with HIP events on the
  * engine's own stream: enable, run rounds, read back per-kernel totals */

@@ -118,7 +118,7 @@ def load():
     L.csl_frontier_device_ptr.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.csl_copy_frontier.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, p64, C.c_int64]
     L.csl_copy_frontier.restype = C.c_int64
-    L.csl_hip_stream.argtypes = [vp, C.POINTER(vp)]
+    L.csl_hip_stream.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     L.csl_timing_enable.argtypes = [vp, C.c_int32]
     L.csl_timing_read.argtypes = [vp, C.POINTER(C.c_double), p64]
     L.csl_kernel_name.argtypes = [C.c_int32]
@@ -249,9 +249,9 @@ class Engine:
         _check(load().csl_frontier_device_ptr(self._h, slot, stream, layer, C.byref(p)))
         return p.value
 
-    def hip_stream(self):
+    def hip_stream(self, slot=0):
         p = C.c_void_p()
-        _check(load().csl_hip_stream(self._h, C.byref(p)))
+        _check(load().csl_hip_stream(self._h, slot, C.byref(p)))
         return p.value
 
     def fetch_sample(self, stream=0, slot=0):

@@ -177,8 +177,7 @@ struct BatchDesc {
 
 __global__ __launch_bounds__(TN) void k_seeds(const long long* __restrict__ nodes, const BatchDesc* __restrict__ desc,
                                               uint32_t* fr0, size_t fr0_stride, uint32_t* fsize,
-                                              csl_sample_meta* meta, const unsigned long long* rngpos,
-                                              uint32_t N, int n_layers) {
+                                              csl_sample_meta* meta, uint32_t N, int n_layers) {
   const int s = blockIdx.y;
   const BatchDesc d = desc[s];
   const uint32_t i = blockIdx.x * TN + threadIdx.x;
@@ -187,8 +186,6 @@ __global__ __launch_bounds__(TN) void k_seeds(const long long* __restrict__ node
     for (int l = 1; l <= n_layers; l++) fsize[s * (CSL_MAX_LAYERS + 1) + l] = 0;
     meta[s].error = 0;
     meta[s].n_seeds = (uint32_t)d.count;
-    meta[s].rng_begin = rngpos[s];
-    meta[s].rng_end = rngpos[s];
   }
   if (i < (uint32_t)d.count) {
     long long v = nodes[d.offset + i];
@@ -288,6 +285,7 @@ __global__ __launch_bounds__(TN) void k_scan(LArgs a) {
       const unsigned long long draws = (unsigned long long)s_tot[K_NEED] * a.fanout;
       a.rngbase[s] = base;
       a.rngpos[s] = base + draws;
+      if (a.layer == 0) a.meta[s].rng_begin = base;
       a.meta[s].rng_end = base + draws;
       m.frontier = F;
       m.draws = (uint32_t)draws;
@@ -1212,8 +1210,15 @@ struct csl_engine {
   int S, P, L, slots;
   uint32_t N;
   size_t E;
+  // rounds alternate between two HIP streams and two scratch sets (when there are >= 2 result
+  // slots): the latency-bound small layers of round r+1 run beside the big last layer of round r.
+  // `stream` aliases streams[0].
   hipStream_t stream = nullptr, rng_stream = nullptr;
+  hipStream_t streams[2] = {nullptr, nullptr};
+  int nsets = 1;
   hipEvent_t rng_event = nullptr;
+  hipEvent_t chain_event = nullptr;  // recorded after a round's last rng-position update
+  bool chain_valid = false;
   std::vector<hipEvent_t> slot_event;  // recorded after the round that fills a result slot
   std::vector<char> slot_pending;
   // graph
@@ -1373,7 +1378,7 @@ int ensure_rng(csl_engine* e) {
   if (target > lo + e->ring_words) {
     // upper bounds drift above the real positions; resync before giving up
     if (e->dirty) {
-      HIPCHECK(hipStreamSynchronize(e->stream));
+      for (int k = 0; k < e->nsets; k++) HIPCHECK(hipStreamSynchronize(e->streams[k]));
       e->dirty = false;
       int r = collect_timing(e);
       if (r) return r;
@@ -1405,7 +1410,6 @@ int ensure_rng(csl_engine* e) {
   e->gen_hi += (uint64_t)nblocks * 624ull;
   if (e->gen_hi < need_hi) return fail(CSL_E_INVALID, "mt19937 ring too small for one round");
   HIPCHECK(hipEventRecord(e->rng_event, e->rng_stream));
-  HIPCHECK(hipStreamWaitEvent(e->stream, e->rng_event, 0));
   return 0;
 }
 
@@ -1413,17 +1417,22 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
   const int S = e->S, L = e->L;
   int r = ensure_rng(e);
   if (r) return r;
+  const int set = e->nsets > 1 ? (slot & 1) : 0;
+  hipStream_t st = e->streams[set];
+  const size_t sF = (size_t)set * S * e->fcap_max, sC = (size_t)set * S * e->ccap_max;
+  uint32_t* fsize = e->fsize + (size_t)set * S * (CSL_MAX_LAYERS + 1);
+  // the mt19937 window this round may read has been requested on the rng stream
+  HIPCHECK(hipStreamWaitEvent(st, e->rng_event, 0));
   // the generator may only overwrite ring words below every stream's position
   const unsigned long long gen_lo = e->gen_hi > e->ring_words ? e->gen_hi - e->ring_words : 0;
   BatchDesc* dd = e->desc_dev + (size_t)slot * S;
-  HIPCHECK(hipMemcpyAsync(dd, e->desc_host + (size_t)slot * S, sizeof(BatchDesc) * S, hipMemcpyHostToDevice,
-                          e->stream));
+  HIPCHECK(hipMemcpyAsync(dd, e->desc_host + (size_t)slot * S, sizeof(BatchDesc) * S, hipMemcpyHostToDevice, st));
   csl_sample_meta* meta = e->meta + (size_t)slot * S;
   {
-    Timed t(e, KN_SEEDS, e->stream);
+    Timed t(e, KN_SEEDS, st);
     dim3 grid((unsigned)((e->fcap[0] + TN - 1) / TN), S);
-    hipLaunchKernelGGL(k_seeds, grid, dim3(TN), 0, e->stream, nodes_dev, dd,
-                       e->fr[0] + (size_t)slot * S * e->fcap[0], e->fcap[0], e->fsize, meta, e->rngpos, e->N, L);
+    hipLaunchKernelGGL(k_seeds, grid, dim3(TN), 0, st, nodes_dev, dd,
+                       e->fr[0] + (size_t)slot * S * e->fcap[0], e->fcap[0], fsize, meta, e->N, L);
   }
   for (int l = 0; l < L; l++) {
     LArgs a;
@@ -1438,30 +1447,30 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.gen_lo = gen_lo;
     a.gen_hi = e->gen_hi;
     a.rngpos = e->rngpos;
-    a.rngbase = e->rngbase;
+    a.rngbase = e->rngbase + (size_t)set * S;
     a.fr_in = e->fr[l] + (size_t)slot * S * e->fcap[l];
     a.fr_out = e->fr[l + 1] + (size_t)slot * S * e->fcap[l + 1];
     a.fr_in_stride = e->fcap[l];
     a.fr_out_stride = e->fcap[l + 1];
     a.fr_out_cap = (uint32_t)e->fcap[l + 1];
-    a.ninfo = e->ninfo;
-    a.hasedge = e->hasedge;
-    a.selfpos = e->selfpos;
-    a.firstpos = e->firstpos;
+    a.ninfo = e->ninfo + sF;
+    a.hasedge = e->hasedge + sF;
+    a.selfpos = e->selfpos + sF;
+    a.firstpos = e->firstpos + sF;
     a.fcap = e->fcap_max;
-    a.cand = e->cand;
-    a.cflag = e->cflag;
-    a.crank = e->crank;
-    a.queue = e->queue;
+    a.cand = e->cand + sC;
+    a.cflag = e->cflag + sC;
+    a.crank = e->crank + sC;
+    a.queue = e->queue + sC;
     a.ccap = e->ccap_max;
-    a.nbk = e->nbk;
-    a.bcnt = e->bcnt;
-    a.bcur = e->bcur;
+    a.nbk = e->nbk + (size_t)set * S;
+    a.bcnt = e->bcnt + (size_t)set * S * (e->nbmax + 1);
+    a.bcur = e->bcur + (size_t)set * S * e->nbmax;
     a.nbmax = e->nbmax;
-    a.tcnt = e->tcnt;
+    a.tcnt = e->tcnt + (size_t)set * S * e->nk * e->tmax;
     a.tmax = e->tmax;
     a.nk = e->nk;
-    a.fsize = e->fsize;
+    a.fsize = fsize;
     a.meta = meta;
     a.arena = e->arena[l] + (size_t)slot * S * e->arena_stride[l];
     a.arena_stride = e->arena_stride[l];
@@ -1473,8 +1482,8 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.S = (uint32_t)S;
     a.last = l == L - 1 ? 1u : 0u;
     a.graph = e->cfg.mode == CSL_MODE_GRAPH ? 1u : 0u;
-    a.ecnt = e->ecnt;
-    a.srcpos = e->srcpos;
+    a.ecnt = e->ecnt ? e->ecnt + sF * e->P : nullptr;
+    a.srcpos = e->srcpos ? e->srcpos + sC : nullptr;
     const dim3 blk(TN);
     const unsigned tiles_in = (unsigned)((e->fcap[l] + TN - 1) / TN);
     const size_t ccap_l = (size_t)tiles_in * TN * a.W;
@@ -1490,53 +1499,60 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     const dim3 grid_bucket(xg * nb_l);
     const size_t lds_hist = (size_t)e->nbmax * sizeof(uint32_t);
     {
-      Timed t(e, KN_DEGREE, e->stream);
-      hipLaunchKernelGGL(k_degree, grid_in, blk, 0, e->stream, a);
+      Timed t(e, KN_DEGREE, st);
+      hipLaunchKernelGGL(k_degree, grid_in, blk, 0, st, a);
+    }
+    // the stream's mt19937 position is handed from round to round: this round's first update
+    // waits for the previous round's last one (its k_seeds / first k_degree did not have to)
+    if (l == 0 && e->nsets > 1 && e->chain_valid) HIPCHECK(hipStreamWaitEvent(st, e->chain_event, 0));
+    {
+      Timed t(e, KN_SCAN_A, st);
+      hipLaunchKernelGGL(k_scan<0>, dim3(S), blk, 0, st, a);
+    }
+    if (l == L - 1 && e->nsets > 1) {
+      HIPCHECK(hipEventRecord(e->chain_event, st));
+      e->chain_valid = true;
     }
     {
-      Timed t(e, KN_SCAN_A, e->stream);
-      hipLaunchKernelGGL(k_scan<0>, dim3(S), blk, 0, e->stream, a);
+      Timed t(e, KN_SAMPLE, st);
+      hipLaunchKernelGGL(k_sample, grid_sample, blk, lds_hist, st, a);
     }
     {
-      Timed t(e, KN_SAMPLE, e->stream);
-      hipLaunchKernelGGL(k_sample, grid_sample, blk, lds_hist, e->stream, a);
+      Timed t(e, KN_SCAN_Q, st);
+      hipLaunchKernelGGL(k_scan_buckets, dim3(S), blk, 0, st, a);
     }
     {
-      Timed t(e, KN_SCAN_Q, e->stream);
-      hipLaunchKernelGGL(k_scan_buckets, dim3(S), blk, 0, e->stream, a);
+      Timed t(e, KN_SCATTER, st);
+      hipLaunchKernelGGL(k_scatter, grid_scatter, blk, e->scatter_lds, st, a);
     }
     {
-      Timed t(e, KN_SCATTER, e->stream);
-      hipLaunchKernelGGL(k_scatter, grid_scatter, blk, e->scatter_lds, e->stream, a);
+      Timed t(e, KN_BUCKET, st);
+      hipLaunchKernelGGL(k_bucket, grid_bucket, dim3(BT), 0, st, a);
     }
     {
-      Timed t(e, KN_BUCKET, e->stream);
-      hipLaunchKernelGGL(k_bucket, grid_bucket, dim3(BT), 0, e->stream, a);
+      Timed t(e, KN_COUNT, st);
+      hipLaunchKernelGGL(k_count, dim3(xg * ((tiles_in + NW - 1) / NW)), blk, 0, st, a);
     }
     {
-      Timed t(e, KN_COUNT, e->stream);
-      hipLaunchKernelGGL(k_count, dim3(xg * ((tiles_in + NW - 1) / NW)), blk, 0, e->stream, a);
+      Timed t(e, KN_SCAN_B, st);
+      hipLaunchKernelGGL(k_scan<1>, dim3(S), blk, 0, st, a);
     }
     {
-      Timed t(e, KN_SCAN_B, e->stream);
-      hipLaunchKernelGGL(k_scan<1>, dim3(S), blk, 0, e->stream, a);
-    }
-    {
-      Timed t(e, KN_EMIT, e->stream);
-      hipLaunchKernelGGL(k_emit, grid_in, blk, 0, e->stream, a);
+      Timed t(e, KN_EMIT, st);
+      hipLaunchKernelGGL(k_emit, grid_in, blk, 0, st, a);
     }
     if (a.graph) {
-      Timed t(e, KN_EDGES, e->stream);
-      hipLaunchKernelGGL(k_graph, grid_in, blk, 0, e->stream, a);
+      Timed t(e, KN_EDGES, st);
+      hipLaunchKernelGGL(k_graph, grid_in, blk, 0, st, a);
     }
     {
-      Timed t(e, KN_SELFIN, e->stream);
-      hipLaunchKernelGGL(k_selfin, grid_in, blk, 0, e->stream, a);
+      Timed t(e, KN_SELFIN, st);
+      hipLaunchKernelGGL(k_selfin, grid_in, blk, 0, st, a);
     }
   }
   HIPCHECK(hipGetLastError());
   for (int s = 0; s < n_batches && s < S; s++) e->pos_ub[s] += e->worst_draws;
-  HIPCHECK(hipEventRecord(e->slot_event[slot], e->stream));
+  HIPCHECK(hipEventRecord(e->slot_event[slot], st));
   e->slot_pending[slot] = 1;
   e->dirty = true;
   e->meta_valid[slot] = 0;
@@ -1554,7 +1570,8 @@ const char* csl_kernel_name(int32_t k) { return (k >= 0 && k < CSL_NUM_KERNELS) 
 void csl_destroy(csl_engine* e) {
   if (!e) return;
   hipSetDevice(e->cfg.device);
-  if (e->stream) hipStreamSynchronize(e->stream);
+  for (int k = 0; k < 2; k++)
+    if (e->streams[k]) hipStreamSynchronize(e->streams[k]);
   if (e->rng_stream) hipStreamSynchronize(e->rng_stream);
   for (auto& te : e->timed) {
     hipEventDestroy(te.a);
@@ -1575,8 +1592,10 @@ void csl_destroy(csl_engine* e) {
   if (e->fetch_host) hipHostFree(e->fetch_host);
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
   if (e->rng_event) hipEventDestroy(e->rng_event);
+  if (e->chain_event) hipEventDestroy(e->chain_event);
   for (auto ev : e->slot_event) hipEventDestroy(ev);
-  if (e->stream) hipStreamDestroy(e->stream);
+  for (int k = 0; k < 2; k++)
+    if (e->streams[k]) hipStreamDestroy(e->streams[k]);
   if (e->rng_stream) hipStreamDestroy(e->rng_stream);
   delete e;
 }
@@ -1588,9 +1607,12 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   e->N = (uint32_t)cfg->num_nodes;
   e->E = (size_t)cfg->num_edges;
   HIPCHECK(hipSetDevice(cfg->device));
-  HIPCHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->nsets = cfg->n_slots >= 2 ? 2 : 1;
+  for (int k = 0; k < e->nsets; k++) HIPCHECK(hipStreamCreateWithFlags(&e->streams[k], hipStreamNonBlocking));
+  e->stream = e->streams[0];
   HIPCHECK(hipStreamCreateWithFlags(&e->rng_stream, hipStreamNonBlocking));
   HIPCHECK(hipEventCreateWithFlags(&e->rng_event, hipEventDisableTiming));
+  HIPCHECK(hipEventCreateWithFlags(&e->chain_event, hipEventDisableTiming));
   const size_t N = e->N;
   // ---- graph upload + packing (int64 CSR -> rowinfo / u32 indices)
   DMALLOC(e->rowinfo, N);
@@ -1647,18 +1669,18 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   e->nk = (uint32_t)NKINDS(P, cfg->mode == CSL_MODE_GRAPH);
   // ---- per-stream scratch
   for (int l = 0; l <= L; l++) DMALLOC(e->fr[l], (size_t)e->slots * S * e->fcap[l]);  // [slot][S][fcap]
-  DMALLOC(e->ninfo, (size_t)S * e->fcap_max);
-  DMALLOC(e->hasedge, (size_t)S * e->fcap_max);
-  DMALLOC(e->selfpos, (size_t)S * e->fcap_max);
-  DMALLOC(e->firstpos, (size_t)S * e->fcap_max);
-  DMALLOC(e->cand, (size_t)S * e->ccap_max);
-  DMALLOC(e->cflag, (size_t)S * e->ccap_max);
-  DMALLOC(e->crank, (size_t)S * e->ccap_max);
+  DMALLOC(e->ninfo, e->nsets * (size_t)S * e->fcap_max);
+  DMALLOC(e->hasedge, e->nsets * (size_t)S * e->fcap_max);
+  DMALLOC(e->selfpos, e->nsets * (size_t)S * e->fcap_max);
+  DMALLOC(e->firstpos, e->nsets * (size_t)S * e->fcap_max);
+  DMALLOC(e->cand, e->nsets * (size_t)S * e->ccap_max);
+  DMALLOC(e->cflag, e->nsets * (size_t)S * e->ccap_max);
+  DMALLOC(e->crank, e->nsets * (size_t)S * e->ccap_max);
   if (cfg->mode == CSL_MODE_GRAPH) {
-    DMALLOC(e->ecnt, (size_t)S * e->fcap_max * P);
-    DMALLOC(e->srcpos, (size_t)S * e->ccap_max);
+    DMALLOC(e->ecnt, e->nsets * (size_t)S * e->fcap_max * P);
+    DMALLOC(e->srcpos, e->nsets * (size_t)S * e->ccap_max);
   }
-  DMALLOC(e->queue, (size_t)S * e->ccap_max);
+  DMALLOC(e->queue, e->nsets * (size_t)S * e->ccap_max);
   e->nbmax = (uint32_t)((e->ccap_max + QMEAN - 1) / QMEAN);
   if (e->nbmax < 1) e->nbmax = 1;
   if (e->nbmax > 8192)
@@ -1667,15 +1689,15 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   e->scatter_lds = (((size_t)3 * e->nbmax + 1) & ~(size_t)1) * sizeof(uint32_t) + (size_t)SCT * sizeof(uint2);
   if (e->scatter_lds > 150 * 1024) return fail(CSL_E_INVALID, "k_scatter needs %zu bytes of LDS", e->scatter_lds);
   HIPCHECK(hipFuncSetAttribute((const void*)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->scatter_lds));
-  DMALLOC(e->nbk, (size_t)S);
-  DMALLOC(e->bcnt, (size_t)S * (e->nbmax + 1));
-  DMALLOC(e->bcur, (size_t)S * e->nbmax);
-  DMALLOC(e->tcnt, (size_t)S * e->nk * e->tmax);
-  DMALLOC(e->fsize, (size_t)S * (CSL_MAX_LAYERS + 1));
+  DMALLOC(e->nbk, e->nsets * (size_t)S);
+  DMALLOC(e->bcnt, e->nsets * (size_t)S * (e->nbmax + 1));
+  DMALLOC(e->bcur, e->nsets * (size_t)S * e->nbmax);
+  DMALLOC(e->tcnt, e->nsets * (size_t)S * e->nk * e->tmax);
+  DMALLOC(e->fsize, e->nsets * (size_t)S * (CSL_MAX_LAYERS + 1));
   DMALLOC(e->rngpos, (size_t)S);
-  DMALLOC(e->rngbase, (size_t)S);
+  DMALLOC(e->rngbase, e->nsets * (size_t)S);
   HIPCHECK(hipMemsetAsync(e->rngpos, 0, sizeof(unsigned long long) * S, e->stream));
-  HIPCHECK(hipMemsetAsync(e->fsize, 0, sizeof(uint32_t) * S * (CSL_MAX_LAYERS + 1), e->stream));
+  HIPCHECK(hipMemsetAsync(e->fsize, 0, sizeof(uint32_t) * e->nsets * S * (CSL_MAX_LAYERS + 1), e->stream));
   // ---- result arenas
   DMALLOC(e->meta, (size_t)e->slots * S);
   HIPCHECK(hipMemsetAsync(e->meta, 0, sizeof(csl_sample_meta) * e->slots * S, e->stream));
@@ -1791,7 +1813,7 @@ int csl_create(const csl_config* cfg, csl_engine** out) {
 int csl_set_nodes(csl_engine* e, const int64_t* host_nodes, int64_t n) {
   if (!e || !host_nodes || n < 0) return fail(CSL_E_INVALID, "bad argument");
   HIPCHECK(hipSetDevice(e->cfg.device));
-  HIPCHECK(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < e->nsets; k++) HIPCHECK(hipStreamSynchronize(e->streams[k]));
   if (e->nodes) {
     hipFree(e->nodes);
     e->dev_bytes -= (int64_t)(e->n_nodes * sizeof(long long));
@@ -1843,7 +1865,7 @@ int csl_submit_seeds(csl_engine* e, const int64_t* seeds, const int64_t* offsets
     }
   }
   // the staging buffer is reused: wait for rounds that may still read it
-  HIPCHECK(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < e->nsets; k++) HIPCHECK(hipStreamSynchronize(e->streams[k]));
   if ((size_t)total > e->seedbuf_cap) {
     if (e->seedbuf) {
       hipFree(e->seedbuf);
@@ -1861,7 +1883,7 @@ int csl_submit_seeds(csl_engine* e, const int64_t* seeds, const int64_t* offsets
 int csl_sync(csl_engine* e) {
   if (!e) return fail(CSL_E_INVALID, "null engine");
   HIPCHECK(hipSetDevice(e->cfg.device));
-  HIPCHECK(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < e->nsets; k++) HIPCHECK(hipStreamSynchronize(e->streams[k]));
   HIPCHECK(hipStreamSynchronize(e->rng_stream));
   e->dirty = false;
   std::fill(e->slot_pending.begin(), e->slot_pending.end(), 0);
@@ -1991,9 +2013,10 @@ int64_t csl_copy_frontier(csl_engine* e, int32_t slot, int32_t stream, int32_t l
   return n;
 }
 
-int csl_hip_stream(csl_engine* e, void** out) {
+int csl_hip_stream(csl_engine* e, int32_t slot, void** out) {
   if (!e || !out) return fail(CSL_E_INVALID, "null argument");
-  *out = (void*)e->stream;
+  if (slot < 0 || slot >= e->slots) return fail(CSL_E_INVALID, "slot out of range");
+  *out = (void*)e->streams[e->nsets > 1 ? (slot & 1) : 0];
   return 0;
 }
 
