@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--serial-rounds", action="store_true",
+                    help="no overlap of consecutive rounds (profiling: undisturbed per-kernel durations)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--e2e-steps", type=int, default=64,
                     help="end-to-end training minibatches for the secondary iters/s figure (0 = skip)")
@@ -161,8 +163,9 @@ def main():
     N = indptr.shape[0] - 1
     S, B, P = args.streams, args.batch, args.parts
     perm = np.random.default_rng(1).permutation(N).astype(np.int64)
+    eng_flags = _abi.FLAG_SERIAL_ROUNDS if args.serial_rounds else 0
     eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2,
-                      device=device)
+                      device=device, flags=eng_flags)
     eng.set_nodes(perm)
     from cslicer import shard
     n_rounds, n_batches = shard.rounds_per_epoch(N, B, S)  # full rounds only: every step does S minibatches
@@ -235,6 +238,7 @@ def main():
                         % (N, args.mean_deg, args.graph_seed, "/".join(map(str, fan)), B, P, P),
             "streams": S,
             "minibatches_per_step": S,
+            "round_overlap": not args.serial_rounds,
             "exported_lists": "int64",
             "sampled_edges_per_minibatch": edges_per_round / S,
         },
@@ -268,7 +272,7 @@ def main():
         }
         tr.close()
         eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2,
-                          device=device) if (rank == 0 and not args.no_kernel_timing) else None
+                          device=device, flags=eng_flags) if (rank == 0 and not args.no_kernel_timing) else None
         if eng is not None:
             eng.set_nodes(perm)
             for w in range(args.warmup):

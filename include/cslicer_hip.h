@@ -111,8 +111,15 @@ typedef struct {
   /* optional frontier capacity per layer input (0 => worst case batch*prod(fanout+1)) */
   int64_t frontier_cap[CSL_MAX_LAYERS + 1];
   int32_t mode;              /* CSL_MODE_STRICT (0) or CSL_MODE_GRAPH */
-  int32_t reserved;
+  int32_t flags;             /* CSL_FLAG_* */
 } csl_config;
+
+/* csl_config.flags */
+enum {
+  /* run every round on one HIP stream (no overlap of consecutive rounds): per-kernel
+   * durations are then not stretched by a neighbouring round; used for profiling */
+  CSL_FLAG_SERIAL_ROUNDS = 1
+};
 
 typedef struct {
   uint32_t frontier;         /* |in| of this layer (slice_layer's `in`, slicer.cpp:25) */

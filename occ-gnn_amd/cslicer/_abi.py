@@ -19,6 +19,7 @@ NUM_KERNELS = 13
 (IN_NODES, OUT_NODES, OWNED_OUT_NODES, SELF_IDS_IN, SELF_IDS_OUT, TO_IDS, FROM_IDS,
  INDPTR, INDICES, OWNED_DEGREE) = range(10)
 MODE_STRICT, MODE_GRAPH = 0, 1
+FLAG_SERIAL_ROUNDS = 1
 LIST_KINDS = {
     "in_nodes": IN_NODES, "out_nodes": OUT_NODES, "owned_out_nodes": OWNED_OUT_NODES,
     "self_ids_in": SELF_IDS_IN, "self_ids_out": SELF_IDS_OUT, "to_ids": TO_IDS, "from_ids": FROM_IDS,
@@ -54,7 +55,7 @@ class Config(C.Structure):
         ("rng_ring_log2", C.c_uint32),
         ("frontier_cap", C.c_int64 * (MAX_LAYERS + 1)),
         ("mode", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -143,7 +144,7 @@ class Engine:
 
     def __init__(self, indptr, indices, n_parts=4, fanouts=(10, 10, 10), max_batch=1024,
                  n_streams=1, n_slots=1, workload=None, device=0, rng_seed=5489,
-                 rng_ring_log2=0, frontier_cap=None, mode=MODE_STRICT):
+                 rng_ring_log2=0, frontier_cap=None, mode=MODE_STRICT, flags=0):
         L = load()
         self._h = None
         self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
@@ -173,6 +174,7 @@ class Engine:
         cfg.rng_seed = rng_seed
         cfg.rng_ring_log2 = rng_ring_log2
         cfg.mode = mode
+        cfg.flags = flags
         self.mode = mode
         if frontier_cap is not None:
             for l, c in enumerate(frontier_cap):

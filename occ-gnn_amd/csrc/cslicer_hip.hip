@@ -1417,7 +1417,8 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
   const int S = e->S, L = e->L;
   int r = ensure_rng(e);
   if (r) return r;
-  const int set = e->nsets > 1 ? (slot & 1) : 0;
+  // per-kernel timing wants undisturbed kernels: timed rounds all run on stream 0
+  const int set = (e->nsets > 1 && !e->timing) ? (slot & 1) : 0;
   hipStream_t st = e->streams[set];
   const size_t sF = (size_t)set * S * e->fcap_max, sC = (size_t)set * S * e->ccap_max;
   uint32_t* fsize = e->fsize + (size_t)set * S * (CSL_MAX_LAYERS + 1);
@@ -1607,7 +1608,7 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   e->N = (uint32_t)cfg->num_nodes;
   e->E = (size_t)cfg->num_edges;
   HIPCHECK(hipSetDevice(cfg->device));
-  e->nsets = cfg->n_slots >= 2 ? 2 : 1;
+  e->nsets = (cfg->n_slots >= 2 && !(cfg->flags & CSL_FLAG_SERIAL_ROUNDS)) ? 2 : 1;
   for (int k = 0; k < e->nsets; k++) HIPCHECK(hipStreamCreateWithFlags(&e->streams[k], hipStreamNonBlocking));
   e->stream = e->streams[0];
   HIPCHECK(hipStreamCreateWithFlags(&e->rng_stream, hipStreamNonBlocking));

@@ -51,7 +51,7 @@ def main():
     with open(os.path.join(dst, "summary.md"), "w") as f:
         f.write("# rocprofv3 summary: %s\n\n" % os.path.basename(src))
         f.write("Command: `profiles/run_profiles.sh` (bench.py --steps 10 --warmup 3 --no-cpu-baseline "
-                "--no-kernel-timing; three separate runs: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE).\n\n")
+                "--no-kernel-timing --serial-rounds --e2e-steps 0; three separate runs: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE).\n\n")
         f.write("FETCH_SIZE / WRITE_SIZE are rocprofv3's raw values in KiB, summed over the launches of the run "
                 "(13 rounds x 3 layers = 39 launches per slicer kernel). MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of "
                 "the bytes of a wide coalesced stream (x2 correction); narrow random gathers are uncalibrated, so the "
