@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(HERE), "lib", "libcslicer_hip.so")
+# CSLICER_LIB: alternative build of the same library (tuning sweeps); default is the in-tree build
+LIB_PATH = os.environ.get("CSLICER_LIB") or os.path.join(os.path.dirname(HERE), "lib", "libcslicer_hip.so")
 
 MAX_PARTS = 8
 MAX_LAYERS = 4

@@ -46,11 +46,27 @@ constexpr uint32_t UNSET = 0xFFFFFFFFu;
 
 constexpr int TN = 256;  // frontier nodes per tile == threads per block
 constexpr int NW = TN / 64;
-constexpr int TPB = 4;         // frontier tiles per k_sample block on large layers
-constexpr int HLOG = 12;       // LDS hash table: 2^HLOG slots x 12 B = 48 KiB per block
+// tuning constants (overridable with -D for sweeps; defaults measured best on MI355X, round 1)
+#ifndef CSL_TPB
+#define CSL_TPB 4
+#endif
+#ifndef CSL_HLOG
+#define CSL_HLOG 12
+#endif
+#ifndef CSL_QMEAN
+#define CSL_QMEAN 2048
+#endif
+#ifndef CSL_SCT
+#define CSL_SCT 8192
+#endif
+#ifndef CSL_SU
+#define CSL_SU 1
+#endif
+constexpr int TPB = CSL_TPB;      // frontier tiles per k_sample block on large layers
+constexpr int HLOG = CSL_HLOG;    // LDS hash table: 2^HLOG slots x 12 B = 48 KiB per block
 constexpr int HCAP = 1 << HLOG;
-constexpr int QMEAN = 1536;    // target candidates per bucket (load <= 0.375)
-constexpr int SCT = 8192;      // candidates per k_scatter block
+constexpr int QMEAN = CSL_QMEAN;  // target candidates per bucket (table load <= 0.5)
+constexpr int SCT = CSL_SCT;      // candidates per k_scatter block
 constexpr int DEG_BITS = 24;
 constexpr uint32_t DEG_MASK = (1u << DEG_BITS) - 1;
 
@@ -426,7 +442,7 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
     const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
     const uint32_t ncand = nodes_here * W;
     const size_t cbase = (size_t)s * a.ccap + (size_t)tile * TN * W;
-    constexpr int SU = 4;
+    constexpr int SU = CSL_SU;
     const uint32_t dq = TN / W, dr = TN - dq * W;  // k += TN  =>  node += dq, slot += dr (+carry)
     uint32_t nn = n / W, slot = n - nn * W;
     for (uint32_t k0 = n; k0 < ncand; k0 += TN * SU) {
@@ -751,12 +767,13 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     if (ee.y & SELF_BIT) {
       const uint32_t i = ee.y & ~SELF_BIT;
       const uint32_t c = i * W;
+      // k_sample left every flag byte zero: only candidates that are a first occurrence are written
       if (a.graph) {
         const uint32_t fe = epos == c;  // epos already includes the self entry
-        cflag[c] = (uint8_t)(fe | (fe << 1) | (g << 2));
+        if (fe) cflag[c] = (uint8_t)(fe | (fe << 1) | (g << 2));
       } else {
         const uint32_t newf = epos > c;  // UNSET compares greater than any position
-        cflag[c] = (uint8_t)(newf | (g << 2));
+        if (newf) cflag[c] = (uint8_t)(newf | (g << 2));
       }
       a.firstpos[s * a.fcap + i] = epos;
     } else {
@@ -764,7 +781,7 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
       const uint32_t self = h_self[h];
       const uint32_t fe = epos == c;
       const uint32_t newf = a.graph ? fe : (fe && (self == UNSET || (unsigned long long)self * W > c));
-      cflag[c] = (uint8_t)(newf | (fe << 1) | (g << 2));
+      if (fe) cflag[c] = (uint8_t)(newf | (fe << 1) | (g << 2));
       if (a.graph) a.srcpos[(size_t)s * a.ccap + c] = epos;
     }
   };
