@@ -705,8 +705,14 @@ __device__ __forceinline__ uint32_t ht_find(const uint32_t* h_key, uint32_t val)
   return UNSET;
 }
 
-constexpr int BT = 512;  // threads per k_bucket block: 3 blocks x 8 waves share a CU's LDS
-constexpr int RC = 4;    // queue entries a thread keeps in registers between the two phases
+#ifndef CSL_BT
+#define CSL_BT 512
+#endif
+#ifndef CSL_RC
+#define CSL_RC 4
+#endif
+constexpr int BT = CSL_BT;  // threads per k_bucket block: 3 blocks x 8 waves share a CU's LDS
+constexpr int RC = CSL_RC;  // queue entries a thread keeps in registers between the two phases
 
 __device__ __forceinline__ uint32_t ht_insert(uint32_t* h_key, uint32_t val) {
   uint32_t h = slot_of(val);
@@ -841,7 +847,10 @@ __global__ __launch_bounds__(TN) void k_count(LArgs a) {
 // (bipartite.h:9-26) and of the next frontier.  Positions come from the tile
 // scans (k_scan) plus ballot ranks inside the tile, so every list is in the
 // reference's push order.
-constexpr int EP = 8;  // candidate steps whose flag and id a k_emit thread preloads
+#ifndef CSL_EP
+#define CSL_EP 8
+#endif
+constexpr int EP = CSL_EP;  // candidate steps whose flag and id a k_emit thread preloads
 
 __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   uint32_t tile, s;
