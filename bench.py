@@ -102,7 +102,7 @@ def path_bytes_reference_types(meta_layers, P):
 
 def kernel_bytes_device_layout(name, m, P, layer=0, last=False):
     """Algorithmic bytes one launch of `name` must move for one minibatch-layer,
-    in the engine's own HBM layout (u32 ids internally, int64 exported lists).
+    in the engine's own HBM layout (u32 ids, int32 lists; host exports widen to int64).
     Stated per term in DESIGN.md section 5."""
     F, E, D, U, C = m["F"], m["E"], m["D"], m["U"], m["C"]
     Q = E + F  # bucket queue entries: one per real candidate
@@ -121,10 +121,11 @@ def kernel_bytes_device_layout(name, m, P, layer=0, last=False):
     if name == "k_emit":
         # flags, ids of flagged candidates, next frontier, in_nodes + ranks, node lists,
         # and (not on the last layer) the next layer's rowinfo gather + ninfo store
-        return (C * 1 + (U + m["in_total"]) * 4 + U * 4 + m["in_total"] * (8 + 4)
-                + F * (4 + 4) + m["node_lists"] * 8 + F * 4 + (0 if last else U * 16))
+        # (lists are int32 on the device)
+        return (C * 1 + (U + m["in_total"]) * 4 + U * 4 + m["in_total"] * (4 + 4)
+                + F * (4 + 4) + m["node_lists"] * 4 + F * 4 + (0 if last else U * 16))
     if name == "k_selfin":
-        return F * (4 + 4 + 4 + 8)
+        return F * (4 + 4 + 4 + 4)
     return 0
 
 
@@ -239,7 +240,7 @@ def main():
             "streams": S,
             "minibatches_per_step": S,
             "round_overlap": not args.serial_rounds,
-            "exported_lists": "int64",
+            "device_lists": "int32 (host exports widen to the reference's int64)",
             "sampled_edges_per_minibatch": edges_per_round / S,
         },
     }

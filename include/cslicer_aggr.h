@@ -12,7 +12,7 @@
  *                             per-GPU means, bipartite.py:98; sums + one division is the
  *                             mathematically intended mean)
  *
- * All pointers are DEVICE pointers; index arrays are int64 (the slices' own type); `stream`
+ * All pointers are DEVICE pointers; index arrays are int32 (the slices' device type); `stream`
  * is a hipStream_t.  fp32 throughout.  Returns 0 or a negative CSL_E_* code (cslicer_hip.h).
  */
 #ifndef CSLICER_AGGR_H
@@ -26,25 +26,25 @@ extern "C" {
 
 /* out[r, :] = sum over e in [indptr[row], indptr[row+1]) of x[indices[e], :]
  * row = rows ? rows[r] : r, r in [0, n_rows).  x has `ldx` floats per row, out `ldo`; H <= ldx, ldo. */
-int csl_spmm_sum_f32(const int64_t* indptr, const int64_t* indices, const int64_t* rows, int64_t n_rows,
+int csl_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
                      const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, void* stream);
 
 /* grad_x[indices[e], :] += grad_out[q, :] for every edge e of row = rows ? rows[r] : r,
  * r in [0, n_rows); q = compact ? r : row (compact: grad_out holds only the listed rows). fp32 atomics. */
-int csl_spmm_sum_bwd_f32(const int64_t* indptr, const int64_t* indices, const int64_t* rows, int64_t n_rows,
+int csl_spmm_sum_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
                          const float* grad_out, int64_t ldg, int32_t compact, float* grad_x, int64_t ldx, int32_t H,
                          void* stream);
 
 /* dst[k, :] = idx[k] >= 0 ? src[idx[k], :] : 0 */
-int csl_gather_rows_f32(const float* src, int64_t lds, const int64_t* idx, int64_t n, float* dst, int64_t ldd,
+int csl_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, int64_t n, float* dst, int64_t ldd,
                         int32_t H, void* stream);
 
 /* dst[idx[k], :] += src[k, :]; idx must not repeat inside one call */
-int csl_scatter_add_rows_f32(float* dst, int64_t ldd, const int64_t* idx, int64_t n, const float* src, int64_t lds,
+int csl_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t n, const float* src, int64_t lds,
                              int32_t H, void* stream);
 
 /* x[k, :] /= max(deg[k], 1) */
-int csl_div_rows_f32(float* x, int64_t ldx, const int64_t* deg, int64_t n, int32_t H, void* stream);
+int csl_div_rows_f32(float* x, int64_t ldx, const int32_t* deg, int64_t n, int32_t H, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@
  *
  * Results of a round stay in device memory (result slot `slot`), in the object
  * layout of BiPartite (bipartite.h:9-26): per layer and per list kind one
- * int64 array holding the lists of parts 0..P-1 back to back, plus an offset
+ * array (int32 on the device) holding the lists of parts 0..P-1 back to back, plus an offset
  * table (csl_layer_meta).  csl_copy_list / csl_list_device_ptr hand them out.
  *
  * All functions return 0 on success, a negative CSL_E_* code on failure;
@@ -189,10 +189,12 @@ int64_t csl_copy_list(csl_engine* e, int32_t slot, int32_t stream, int32_t layer
 int csl_fetch_sample(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta,
                      const int64_t** host_ptr, int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS]);
 
-/* zero-copy surface: device pointer of the kind's int64 array (all parts back
- * to back, offsets in csl_layer_meta.off) */
+/* zero-copy surface: device pointer of the kind's array (all parts back to back,
+ * offsets in csl_layer_meta.off).  On the device the lists are int32 (ids and local
+ * indices are < 2^31, -1 sentinels kept): half the store traffic of the reference's
+ * `long`; the host exports above (csl_copy_list, csl_fetch_sample) widen to int64. */
 int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind,
-                        const int64_t** out);
+                        const int32_t** out);
 /* device pointer of the frontier entering `layer` (0..n_layers; n_layers = the
  * nodes whose features the model reads); uint32 ids; length in meta */
 int csl_frontier_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, const uint32_t** out);

@@ -49,15 +49,15 @@ def _f32(x):
     return x if x.stride(-1) == 1 else x.contiguous()
 
 
-def _i64(x):
-    if x.dtype != torch.int64 or not x.is_cuda:
-        raise TypeError("expected an int64 CUDA tensor")
+def _i32(x):
+    if x.dtype != torch.int32 or not x.is_cuda:
+        raise TypeError("expected an int32 CUDA tensor (the slices' device index type)")
     return x.contiguous()
 
 
 def spmm_sum(indptr, indices, x, n_rows, rows=None, out=None):
     """out[row] = sum of x[indices[e]] over the row's edges (BipartiteGraph.gather, sum form).
-    rows: optional int64 list of the rows to compute (others untouched)."""
+    rows: optional int32 list of the rows to compute (others untouched)."""
     x = _f32(x)
     H = x.shape[1]
     if out is None:
@@ -65,7 +65,7 @@ def spmm_sum(indptr, indices, x, n_rows, rows=None, out=None):
         if rows is not None:
             out.zero_()
     n = n_rows if rows is None else rows.numel()
-    _chk(_lib().csl_spmm_sum_f32(_p(_i64(indptr)), _p(_i64(indices)), _p(rows) if rows is not None else C.c_void_p(0),
+    _chk(_lib().csl_spmm_sum_f32(_p(_i32(indptr)), _p(_i32(indices)), _p(rows) if rows is not None else C.c_void_p(0),
                                  n, _p(x), x.stride(0), _p(out), out.stride(0), H, _stream()), "csl_spmm_sum_f32")
     return out
 
@@ -76,7 +76,7 @@ def spmm_sum_bwd(indptr, indices, grad_out, n_src, rows=None, compact=False, out
     g = _f32(grad_out)
     gx = out if out is not None else torch.zeros((n_src, g.shape[1]), dtype=torch.float32, device=g.device)
     n = g.shape[0] if rows is None else rows.numel()
-    _chk(_lib().csl_spmm_sum_bwd_f32(_p(_i64(indptr)), _p(_i64(indices)),
+    _chk(_lib().csl_spmm_sum_bwd_f32(_p(_i32(indptr)), _p(_i32(indices)),
                                      _p(rows) if rows is not None else C.c_void_p(0), n, _p(g), g.stride(0),
                                      1 if compact else 0, _p(gx), gx.stride(0), g.shape[1], _stream()),
          "csl_spmm_sum_bwd_f32")
@@ -86,7 +86,7 @@ def spmm_sum_bwd(indptr, indices, grad_out, n_src, rows=None, compact=False, out
 def gather_rows(src, idx):
     """dst[k] = src[idx[k]] (zero row for idx -1): pull_for_remotes / self_gather."""
     src = _f32(src)
-    idx = _i64(idx)
+    idx = _i32(idx)
     dst = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
     _chk(_lib().csl_gather_rows_f32(_p(src), src.stride(0), _p(idx), idx.numel(), _p(dst), dst.stride(0),
                                     src.shape[1], _stream()), "csl_gather_rows_f32")
@@ -96,7 +96,7 @@ def gather_rows(src, idx):
 def scatter_add_rows_(dst, idx, src):
     """dst[idx[k]] += src[k] in place (idx unique): push_from_remotes / mergeKernel."""
     src = _f32(src)
-    idx = _i64(idx)
+    idx = _i32(idx)
     if dst.stride(-1) != 1:
         raise ValueError("dst must be row-contiguous")
     _chk(_lib().csl_scatter_add_rows_f32(_p(dst), dst.stride(0), _p(idx), idx.numel(), _p(src), src.stride(0),
@@ -106,7 +106,7 @@ def scatter_add_rows_(dst, idx, src):
 
 def div_rows_(x, deg):
     """x[k] /= max(deg[k], 1) in place."""
-    _chk(_lib().csl_div_rows_f32(_p(x), x.stride(0), _p(_i64(deg)), x.shape[0], x.shape[1], _stream()),
+    _chk(_lib().csl_div_rows_f32(_p(x), x.stride(0), _p(_i32(deg)), x.shape[0], x.shape[1], _stream()),
          "csl_div_rows_f32")
     return x
 

@@ -34,19 +34,19 @@ from . import _abi, aggr
 class _DevArray(object):
     """Zero-copy view of engine memory for torch.as_tensor (__cuda_array_interface__)."""
 
-    def __init__(self, ptr, n, typestr="<i8"):
+    def __init__(self, ptr, n, typestr="<i4"):
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False),
                                          "version": 2, "strides": None}
 
 
-def _view_i64(ptr, n, device):
+def _view_i32(ptr, n, device):
     if n == 0:
-        return torch.zeros(0, dtype=torch.int64, device=device)
+        return torch.zeros(0, dtype=torch.int32, device=device)
     return torch.as_tensor(_DevArray(ptr, n), device=device)
 
 
 class Slice(object):
-    """One BiPartite of graph mode on the device: int64 tensors that alias the engine's arena."""
+    """One BiPartite of graph mode on the device: int32 tensors that alias the engine's arena."""
 
     __slots__ = ("part", "n_parts", "in_nodes", "out_nodes", "indptr", "indices", "owned_out_nodes",
                  "self_ids_in", "owned_degree", "from_ids", "to_ids", "n_in", "n_out", "n_owned")
@@ -69,7 +69,7 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None):
         def seg(kind, g, lo=None, hi=None):
             a = int(lm.off[kind][g]) if lo is None else lo
             b = int(lm.off[kind][g + 1]) if hi is None else hi
-            return _view_i64(base[kind] + 8 * a, b - a, device)
+            return _view_i32(base[kind] + 4 * a, b - a, device)
 
         row = {}
         for g in parts:

@@ -53,15 +53,15 @@ class Trainer(object):
         slices = splitgnn.slices_of(self.eng, stream, slot, parts=[self.rank], device=self.dev)
         self.t_slice += time.perf_counter() - t0
         deep = slices[self.L - 1][self.rank]
-        x = self.feat[deep.in_nodes // self.P]          # gather of owned input features
+        x = self.feat[(deep.in_nodes // self.P).long()]  # gather of owned input features
         t1 = time.perf_counter()
         if self.world > 1:
             logits = self.model.forward_rank(slices, x, self.rank, self.comm, overlap=self.overlap)
         else:
             logits = self.model.forward_parts(slices, {0: x})[0]
         top = slices[0][self.rank]
-        seeds = top.out_nodes[top.owned_out_nodes]        # the seeds this rank owns, frontier order
-        y = self.labels[seeds // self.P]
+        seeds = top.out_nodes[top.owned_out_nodes.long()]  # the seeds this rank owns, frontier order
+        y = self.labels[(seeds // self.P).long()]
         # mean over the WHOLE minibatch: sum of local losses / global seed count
         n_seeds = int(self.eng.meta(stream, slot).n_seeds)
         loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / max(n_seeds, 1)

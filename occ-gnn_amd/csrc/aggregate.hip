@@ -46,9 +46,9 @@ __device__ __forceinline__ void add4(float4& a, const float4 b) {
 
 // G lanes per row (power of two, <= 64); quads beyond G*4 columns are looped
 template <int G>
-__global__ __launch_bounds__(BLK) void k_spmm_sum(const long long* __restrict__ indptr,
-                                                  const long long* __restrict__ indices,
-                                                  const long long* __restrict__ rows, long long n_rows,
+__global__ __launch_bounds__(BLK) void k_spmm_sum(const int* __restrict__ indptr,
+                                                  const int* __restrict__ indices,
+                                                  const int* __restrict__ rows, long long n_rows,
                                                   const float* __restrict__ x, long long ldx, float* __restrict__ out,
                                                   long long ldo, int H, int vec_ok) {
   constexpr int RPB = BLK / G;  // rows per block
@@ -96,9 +96,9 @@ __global__ __launch_bounds__(BLK) void k_spmm_sum(const long long* __restrict__ 
 // backward of the sum-aggregate: one wave per output row walks the row's edges and adds
 // the row's gradient into each source row, 64 consecutive floats per atomic instruction
 // (the shape the chip's memory-side float atomics run fastest at)
-__global__ __launch_bounds__(BLK) void k_spmm_sum_bwd(const long long* __restrict__ indptr,
-                                                      const long long* __restrict__ indices,
-                                                      const long long* __restrict__ rows, long long n_rows,
+__global__ __launch_bounds__(BLK) void k_spmm_sum_bwd(const int* __restrict__ indptr,
+                                                      const int* __restrict__ indices,
+                                                      const int* __restrict__ rows, long long n_rows,
                                                       const float* __restrict__ g, long long ldg, int compact,
                                                       float* __restrict__ gx, long long ldx, int H) {
   const int lane = threadIdx.x & 63;
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(BLK) void k_spmm_sum_bwd(const long long* __restric
 
 template <int G>
 __global__ __launch_bounds__(BLK) void k_gather_rows(const float* __restrict__ src, long long lds,
-                                                     const long long* __restrict__ idx, long long n,
+                                                     const int* __restrict__ idx, long long n,
                                                      float* __restrict__ dst, long long ldd, int H, int vec_ok) {
   constexpr int RPB = BLK / G;
   const int lane = threadIdx.x % G;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BLK) void k_gather_rows(const float* __restrict__ s
 
 template <int G>
 __global__ __launch_bounds__(BLK) void k_scatter_add_rows(float* __restrict__ dst, long long ldd,
-                                                          const long long* __restrict__ idx, long long n,
+                                                          const int* __restrict__ idx, long long n,
                                                           const float* __restrict__ src, long long lds, int H,
                                                           int vec_ok) {
   constexpr int RPB = BLK / G;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(BLK) void k_scatter_add_rows(float* __restrict__ ds
 
 template <int G>
 __global__ __launch_bounds__(BLK) void k_div_rows(float* __restrict__ x, long long ldx,
-                                                  const long long* __restrict__ deg, long long n, int H, int vec_ok) {
+                                                  const int* __restrict__ deg, long long n, int H, int vec_ok) {
   constexpr int RPB = BLK / G;
   const int lane = threadIdx.x % G;
   const long long k = (long long)blockIdx.x * RPB + threadIdx.x / G;
@@ -205,56 +205,56 @@ int done() { return hipGetLastError() == hipSuccess ? CSL_OK : CSL_E_HIP; }
 
 extern "C" {
 
-int csl_spmm_sum_f32(const int64_t* indptr, const int64_t* indices, const int64_t* rows, int64_t n_rows,
+int csl_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
                      const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, void* stream) {
   if (n_rows < 0 || H < 1 || !indptr || !out || ldx < H || ldo < H) return CSL_E_INVALID;
   if (n_rows == 0) return CSL_OK;
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(x, ldx, out, ldo, H);
-  DISPATCH_G(G, k_spmm_sum, n_rows, (const long long*)indptr, (const long long*)indices, (const long long*)rows,
+  DISPATCH_G(G, k_spmm_sum, n_rows, indptr, indices, rows,
              (long long)n_rows, x, (long long)ldx, out, (long long)ldo, (int)H, v);
   return done();
 }
 
-int csl_spmm_sum_bwd_f32(const int64_t* indptr, const int64_t* indices, const int64_t* rows, int64_t n_rows,
+int csl_spmm_sum_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
                          const float* grad_out, int64_t ldg, int32_t compact, float* grad_x, int64_t ldx, int32_t H,
                          void* stream) {
   if (n_rows < 0 || H < 1 || !indptr || !grad_out || !grad_x) return CSL_E_INVALID;
   if (n_rows == 0) return CSL_OK;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_spmm_sum_bwd, dim3((unsigned)((n_rows + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st,
-                     (const long long*)indptr, (const long long*)indices, (const long long*)rows, (long long)n_rows,
+                     indptr, indices, rows, (long long)n_rows,
                      grad_out, (long long)ldg, (int)compact, grad_x, (long long)ldx, (int)H);
   return done();
 }
 
-int csl_gather_rows_f32(const float* src, int64_t lds, const int64_t* idx, int64_t n, float* dst, int64_t ldd,
+int csl_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, int64_t n, float* dst, int64_t ldd,
                         int32_t H, void* stream) {
   if (n < 0 || H < 1 || !idx || !dst) return CSL_E_INVALID;
   if (n == 0) return CSL_OK;
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(src, lds, dst, ldd, H);
-  DISPATCH_G(G, k_gather_rows, n, src, (long long)lds, (const long long*)idx, (long long)n, dst, (long long)ldd, (int)H, v);
+  DISPATCH_G(G, k_gather_rows, n, src, (long long)lds, idx, (long long)n, dst, (long long)ldd, (int)H, v);
   return done();
 }
 
-int csl_scatter_add_rows_f32(float* dst, int64_t ldd, const int64_t* idx, int64_t n, const float* src, int64_t lds,
+int csl_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t n, const float* src, int64_t lds,
                              int32_t H, void* stream) {
   if (n < 0 || H < 1 || !idx || !dst || !src) return CSL_E_INVALID;
   if (n == 0) return CSL_OK;
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(src, lds, dst, ldd, H);
-  DISPATCH_G(G, k_scatter_add_rows, n, dst, (long long)ldd, (const long long*)idx, (long long)n, src, (long long)lds,
+  DISPATCH_G(G, k_scatter_add_rows, n, dst, (long long)ldd, idx, (long long)n, src, (long long)lds,
              (int)H, v);
   return done();
 }
 
-int csl_div_rows_f32(float* x, int64_t ldx, const int64_t* deg, int64_t n, int32_t H, void* stream) {
+int csl_div_rows_f32(float* x, int64_t ldx, const int32_t* deg, int64_t n, int32_t H, void* stream) {
   if (n < 0 || H < 1 || !x || !deg) return CSL_E_INVALID;
   if (n == 0) return CSL_OK;
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(x, ldx, x, ldx, H);
-  DISPATCH_G(G, k_div_rows, n, x, (long long)ldx, (const long long*)deg, (long long)n, (int)H, v);
+  DISPATCH_G(G, k_div_rows, n, x, (long long)ldx, deg, (long long)n, (int)H, v);
   return done();
 }
 

@@ -129,8 +129,9 @@ struct LArgs {
   uint32_t tmax, nk;
   uint32_t* fsize;              // [S][CSL_MAX_LAYERS+1] frontier sizes
   csl_sample_meta* meta;        // [S] (slot already applied)
-  // result arena of this layer (slot applied): int64 [S][arena_stride]
-  long long* arena;
+  // result arena of this layer (slot applied): int32 [S][arena_stride] (ids and local
+  // indices are < 2^31; host exports widen to the reference's `long`)
+  int* arena;
   size_t arena_stride;
   size_t list_base[CSL_NUM_LISTS];  // element offset of each kind inside a stream's arena
   uint32_t layer, fanout, W;
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   const uint32_t n = threadIdx.x, w = n >> 6;
   const uint32_t W = a.W, P = a.P;
   const csl_layer_meta& m = a.meta[s].layer[a.layer];
-  long long* ar = a.arena + (size_t)s * a.arena_stride;
+  int* ar = a.arena + (size_t)s * a.arena_stride;
   const uint32_t* tc = a.tcnt + (size_t)s * a.nk * a.tmax;
 #define TB(kind) tc[(size_t)(kind)*a.tmax + tile]
   __shared__ uint32_t s_wc[2][NW][1 + CSL_MAX_PARTS];
@@ -930,7 +931,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       uint32_t p = s_run[1 + g] + rE;
       for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][1 + g];
       p += TB(K_IN(P, g));  // local index inside slice g's in_nodes
-      ar[a.list_base[CSL_IN_NODES] + m.off[CSL_IN_NODES][g] + p] = (long long)val;
+      ar[a.list_base[CSL_IN_NODES] + m.off[CSL_IN_NODES][g] + p] = (int)val;
       a.crank[cbase + k] = p;  // DuplicateRemover::replace's lookup value (mask[v]-1)
     }
     __syncthreads();
@@ -982,21 +983,21 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   }
   __syncthreads();
   if (act) {
-    long long outrank_to = -1;
+    int outrank_to = -1;
 #pragma unroll
     for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
       if (g < P && ((hb >> g) & 1u)) {
         uint32_t p = r_out[g];
         for (uint32_t ww = 0; ww < w; ww++) p += s_wn[ww][0 * CSL_MAX_PARTS + g];
         p += TB(K_OUT(P, g));  // local index inside slice g's out_nodes
-        ar[a.list_base[CSL_OUT_NODES] + m.off[CSL_OUT_NODES][g] + p] = (long long)v;
+        ar[a.list_base[CSL_OUT_NODES] + m.off[CSL_OUT_NODES][g] + p] = (int)v;
         if (g == to) {
           outrank_to = p;
         } else if (!a.graph) {
           uint32_t q = r_from[g];
           for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][4 * CSL_MAX_PARTS + g];
           q += TB(K_FROM(P, g));
-          ar[a.list_base[CSL_FROM_IDS] + m.off[CSL_FROM_IDS][g] + q] = (long long)p;
+          ar[a.list_base[CSL_FROM_IDS] + m.off[CSL_FROM_IDS][g] + q] = (int)p;
         }
       }
     }
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
   const uint32_t n = threadIdx.x, w = n >> 6;
   const uint32_t W = a.W, P = a.P;
   const csl_layer_meta& m = a.meta[s].layer[a.layer];
-  long long* ar = a.arena + (size_t)s * a.arena_stride;
+  int* ar = a.arena + (size_t)s * a.arena_stride;
   const uint32_t* tc = a.tcnt + (size_t)s * a.nk * a.tmax;
 #define TB(kind) tc[(size_t)(kind)*a.tmax + tile]
   __shared__ uint32_t s_wo[NW][CSL_MAX_PARTS];                  // out-node counts per wave
@@ -1092,7 +1093,7 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
       rs[g] = q + TB(K_ECNT(P, g));  // first index of this node's row in slice g's indices
       deg += ec[g];
       if ((hb >> g) & 1u)
-        ar[a.list_base[CSL_INDPTR] + m.off[CSL_INDPTR][g] + outrank[g] + 1] = (long long)(rs[g] + ec[g]);
+        ar[a.list_base[CSL_INDPTR] + m.off[CSL_INDPTR][g] + outrank[g] + 1] = (int)(rs[g] + ec[g]);
       if (i == 0) ar[a.list_base[CSL_INDPTR] + m.off[CSL_INDPTR][g]] = 0;
     }
   }
@@ -1102,14 +1103,14 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
       uint32_t q = r_pair[g];
       for (uint32_t ww = 0; ww < w; ww++) q += s_wp[ww][g * CSL_MAX_PARTS + to];
       q += TB(K_PAIR(P, g, to));
-      ar[a.list_base[CSL_FROM_IDS] + m.off[CSL_FROM_IDS][g] + m.pair_off[0][g][to] + q] = (long long)outrank[g];
-      ar[a.list_base[CSL_TO_IDS] + m.off[CSL_TO_IDS][to] + m.pair_off[1][to][g] + q] = (long long)outrank[to];
+      ar[a.list_base[CSL_FROM_IDS] + m.off[CSL_FROM_IDS][g] + m.pair_off[0][g][to] + q] = (int)outrank[g];
+      ar[a.list_base[CSL_TO_IDS] + m.off[CSL_TO_IDS][to] + m.pair_off[1][to][g] + q] = (int)outrank[to];
     }
   }
   // mean divisor, next to owned_out_nodes (same order as self_ids_*)
   {
     const uint32_t q = a.selfpos[s * a.fcap + i] - m.off[CSL_SELF_IDS_OUT][to];
-    ar[a.list_base[CSL_OWNED_DEGREE] + m.off[CSL_OWNED_DEGREE][to] + q] = (long long)deg;
+    ar[a.list_base[CSL_OWNED_DEGREE] + m.off[CSL_OWNED_DEGREE][to] + q] = (int)deg;
   }
   // the node's edges, sampling order: local index of each source inside its slice
   const size_t cb = (size_t)s * a.ccap + (size_t)i * W;
@@ -1126,7 +1127,7 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
         rs[gg]++;
       }
     }
-    ar[a.list_base[CSL_INDICES] + m.off[CSL_INDICES][g] + pos] = (long long)rank;
+    ar[a.list_base[CSL_INDICES] + m.off[CSL_INDICES][g] + pos] = (int)rank;
   }
 #undef TB
 }
@@ -1141,9 +1142,9 @@ __global__ __launch_bounds__(TN) void k_selfin(LArgs a) {
   const uint32_t i = bx * TN + threadIdx.x;
   if (i >= F) return;
   const uint32_t fp = a.firstpos[s * a.fcap + i];
-  long long* ar = a.arena + (size_t)s * a.arena_stride;
+  int* ar = a.arena + (size_t)s * a.arena_stride;
   ar[a.list_base[CSL_SELF_IDS_IN] + a.selfpos[s * a.fcap + i]] =
-      fp == UNSET ? -1ll : (long long)a.crank[(size_t)s * a.ccap + fp];
+      fp == UNSET ? -1 : (int)a.crank[(size_t)s * a.ccap + fp];
 }
 
 // ---- k_mt19937_fill: the std::mt19937 stream (slicer.h:33), generated on the
@@ -1289,7 +1290,7 @@ struct csl_engine {
   uint32_t* fsize = nullptr;
   // results
   csl_sample_meta* meta = nullptr;  // [slots][S]
-  long long* arena[CSL_MAX_LAYERS] = {};  // [slots][S][arena_stride[l]]
+  int* arena[CSL_MAX_LAYERS] = {};  // [slots][S][arena_stride[l]], int32
   size_t arena_stride[CSL_MAX_LAYERS];
   size_t list_base[CSL_MAX_LAYERS][CSL_NUM_LISTS];
   size_t list_cap[CSL_MAX_LAYERS][CSL_NUM_LISTS];
@@ -1297,7 +1298,8 @@ struct csl_engine {
   BatchDesc* desc_dev = nullptr;   // [slots][S]
   BatchDesc* desc_host = nullptr;  // pinned, [slots][S]
   // pinned staging for csl_fetch_sample
-  long long* fetch_host = nullptr;
+  int* fetch_stage = nullptr;       // pinned int32 staging
+  long long* fetch_host = nullptr;  // widened copy handed to the caller
   size_t fetch_cap = 0;
   hipStream_t copy_stream = nullptr;
   // host mirror of meta for fetches
@@ -1616,7 +1618,8 @@ void csl_destroy(csl_engine* e) {
   for (int l = 0; l < CSL_MAX_LAYERS; l++)
     if (e->arena[l]) hipFree(e->arena[l]);
   if (e->desc_host) hipHostFree(e->desc_host);
-  if (e->fetch_host) hipHostFree(e->fetch_host);
+  if (e->fetch_stage) hipHostFree(e->fetch_stage);
+  free(e->fetch_host);
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
   if (e->rng_event) hipEventDestroy(e->rng_event);
   if (e->chain_event) hipEventDestroy(e->chain_event);
@@ -1758,7 +1761,7 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
     for (int k = 0; k < CSL_NUM_LISTS; k++) {
       e->list_base[l][k] = o;
       e->list_cap[l][k] = cap[k];
-      o += (cap[k] + 1) & ~(size_t)1;  // keep 16-byte alignment of every list
+      o += (cap[k] + 3) & ~(size_t)3;  // keep 16-byte alignment of every list
     }
     e->arena_stride[l] = o;
     DMALLOC(e->arena[l], (size_t)e->slots * S * o);
@@ -1960,10 +1963,12 @@ int64_t csl_copy_list(csl_engine* e, int32_t slot, int32_t stream, int32_t layer
   const int64_t n = hi - lo;
   if (n > cap) return fail(CSL_E_INVALID, "destination too small: need %lld", (long long)n);
   if (n > 0) {
-    const long long* src = e->arena[layer] + ((size_t)slot * e->S + stream) * e->arena_stride[layer] +
-                           e->list_base[layer][kind] + lo;
-    hipError_t er = hipMemcpy(dst, src, sizeof(long long) * (size_t)n, hipMemcpyDeviceToHost);
+    const int* src = e->arena[layer] + ((size_t)slot * e->S + stream) * e->arena_stride[layer] +
+                     e->list_base[layer][kind] + lo;
+    std::vector<int> tmp((size_t)n);
+    hipError_t er = hipMemcpy(tmp.data(), src, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost);
     if (er != hipSuccess) return fail(CSL_E_HIP, "hipMemcpy failed: %s", hipGetErrorString(er));
+    for (int64_t i = 0; i < n; i++) dst[i] = (int64_t)tmp[(size_t)i];  // widen to the reference's `long`
   }
   return n;
 }
@@ -1981,33 +1986,36 @@ int csl_fetch_sample(csl_engine* e, int32_t slot, int32_t stream, csl_sample_met
   if (!e->fetch_host) {
     size_t cap = 0;
     for (int l = 0; l < e->L; l++) cap += e->arena_stride[l];
-    HIPCHECK(hipHostMalloc((void**)&e->fetch_host, cap * sizeof(long long), hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void**)&e->fetch_stage, cap * sizeof(int), hipHostMallocDefault));
+    e->fetch_host = (long long*)malloc(cap * sizeof(long long));
+    if (!e->fetch_host) return fail(CSL_E_NOMEM, "host allocation failed");
     e->fetch_cap = cap;
     HIPCHECK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
   }
   size_t o = 0;
   for (int l = 0; l < e->L; l++) {
-    const long long* base = e->arena[l] + ((size_t)slot * e->S + stream) * e->arena_stride[l];
+    const int* base = e->arena[l] + ((size_t)slot * e->S + stream) * e->arena_stride[l];
     for (int k = 0; k < CSL_NUM_LISTS; k++) {
       const size_t n = sm.layer[l].off[k][e->P];
       seg[l][k] = (int64_t)o;
       if (n)
-        HIPCHECK(hipMemcpyAsync(e->fetch_host + o, base + e->list_base[l][k], n * sizeof(long long),
+        HIPCHECK(hipMemcpyAsync(e->fetch_stage + o, base + e->list_base[l][k], n * sizeof(int),
                                 hipMemcpyDeviceToHost, e->copy_stream));
       o += n;
     }
   }
   HIPCHECK(hipStreamSynchronize(e->copy_stream));
+  for (size_t i = 0; i < o; i++) e->fetch_host[i] = (long long)e->fetch_stage[i];  // widen to `long`
   *host_ptr = (const int64_t*)e->fetch_host;
   return 0;
 }
 
-int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind, const int64_t** out) {
+int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind, const int32_t** out) {
   if (!e || !out) return fail(CSL_E_INVALID, "null argument");
   if (slot < 0 || slot >= e->slots || stream < 0 || stream >= e->S || layer < 0 || layer >= e->L || kind < 0 ||
       kind >= CSL_NUM_LISTS)
     return fail(CSL_E_INVALID, "index out of range");
-  *out = (const int64_t*)(e->arena[layer] + ((size_t)slot * e->S + stream) * e->arena_stride[layer] +
+  *out = (const int32_t*)(e->arena[layer] + ((size_t)slot * e->S + stream) * e->arena_stride[layer] +
                           e->list_base[layer][kind]);
   return 0;
 }

@@ -33,22 +33,22 @@ def test_spmm_sum_forward_backward(mods, H):
     n_rows, n_src = 777, 500
     indptr, indices = _rand_csr(n_rows, n_src, 15, rng)
     x = torch.randn(n_src, H, dtype=torch.float32)
-    ip, ix = torch.from_numpy(indptr), torch.from_numpy(indices)
+    ip, ix = torch.from_numpy(indptr).int(), torch.from_numpy(indices).int()
     # torch fp32 reference: dense accumulation in edge order
     ref = torch.zeros(n_rows, H)
     rows = torch.repeat_interleave(torch.arange(n_rows), torch.from_numpy(np.diff(indptr)))
-    ref.index_add_(0, rows, x[ix])
+    ref.index_add_(0, rows, x[ix.long()])
     xg = x.cuda().requires_grad_()
     out = aggr.SpmmSum.apply(xg, ip.cuda(), ix.cuda(), n_rows)
     torch.testing.assert_close(out.cpu(), ref, **TOL)
     g = torch.randn(n_rows, H)
     out.backward(g.cuda())
     gref = torch.zeros(n_src, H)
-    gref.index_add_(0, ix, g[rows])
+    gref.index_add_(0, ix.long(), g[rows])
     torch.testing.assert_close(xg.grad.cpu(), gref, rtol=1e-5, atol=2e-5)
     # row subset (boundary rows first)
     sel = torch.from_numpy(rng.choice(n_rows, size=100, replace=False).astype(np.int64))
-    part = aggr.spmm_sum(ip.cuda(), ix.cuda(), x.cuda(), n_rows, rows=sel.cuda())
+    part = aggr.spmm_sum(ip.cuda(), ix.cuda(), x.cuda(), n_rows, rows=sel.int().cuda())
     torch.testing.assert_close(part.cpu()[sel], ref[sel], **TOL)
     mask = torch.ones(n_rows, dtype=torch.bool)
     mask[sel] = False
@@ -63,21 +63,21 @@ def test_gather_scatter_div_rows(mods, H):
     idx = torch.from_numpy(rng.choice(400, size=150, replace=False).astype(np.int64))
     idx_m = idx.clone()
     idx_m[::7] = -1
-    got = aggr.gather_rows(src.cuda(), idx_m.cuda()).cpu()
+    got = aggr.gather_rows(src.cuda(), idx_m.int().cuda()).cpu()
     ref = src[idx_m.clamp(min=0)] * (idx_m >= 0).unsqueeze(1)
     torch.testing.assert_close(got, ref, rtol=0, atol=0)
     dst = torch.randn(400, H)
     add = torch.randn(150, H)
-    got = aggr.scatter_add_rows_(dst.clone().cuda(), idx.cuda(), add.cuda()).cpu()
+    got = aggr.scatter_add_rows_(dst.clone().cuda(), idx.int().cuda(), add.cuda()).cpu()
     ref = dst.clone()
     ref[idx] += add
     torch.testing.assert_close(got, ref, **TOL)
     deg = torch.from_numpy(rng.integers(0, 20, size=400).astype(np.int64))
-    got = aggr.div_rows_(dst.clone().cuda(), deg.cuda()).cpu()
+    got = aggr.div_rows_(dst.clone().cuda(), deg.int().cuda()).cpu()
     torch.testing.assert_close(got, dst / deg.clamp(min=1).unsqueeze(1), **TOL)
     # autograd of the wrappers
     s = src.clone().cuda().requires_grad_()
-    aggr.GatherRows.apply(s, idx.cuda()).sum().backward()
+    aggr.GatherRows.apply(s, idx.int().cuda()).sum().backward()
     gref = torch.zeros(400, H)
     gref[idx] = 1.0
     torch.testing.assert_close(s.grad.cpu(), gref, rtol=0, atol=0)
@@ -119,7 +119,7 @@ def test_split_parallel_sage_matches_dense_reference(mods, P, fan):
     feats = torch.randn(n, F0)
     model = sg.DistSAGEModel(F0, hidden, classes, n_layers=L)
     # each part reads only the features of nodes it owns
-    x = {g: feats[slices[L - 1][g].in_nodes.cpu()].cuda().requires_grad_() for g in range(P)}
+    x = {g: feats[slices[L - 1][g].in_nodes.cpu().long()].cuda().requires_grad_() for g in range(P)}
     for g in range(P):
         assert bool((slices[L - 1][g].in_nodes % P == g).all())
     gm = sg.DistSAGEModel(F0, hidden, classes, n_layers=L).cuda()
@@ -140,6 +140,6 @@ def test_split_parallel_sage_matches_dense_reference(mods, P, fan):
     for (na, pa), (nb, pb) in zip(gm.named_parameters(), model.named_parameters()):
         torch.testing.assert_close(pa.grad.cpu(), pb.grad, rtol=1e-4, atol=1e-5, msg="grad " + na)
     for g in range(P):
-        ids = slices[L - 1][g].in_nodes.cpu()
+        ids = slices[L - 1][g].in_nodes.cpu().long()
         torch.testing.assert_close(x[g].grad.cpu(), fin.grad[ids], rtol=1e-4, atol=1e-5)
     eng.close()

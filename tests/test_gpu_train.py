@@ -100,11 +100,11 @@ def test_two_ranks_match_single_process_two_parts(overlap):
         eng.submit_round(r * 2, 128, 2, slot=r & 1)
         for s in range(2):
             sl = splitgnn.slices_of(eng, s, r & 1)
-            x = {g: ft[sl[1][g].in_nodes] for g in range(2)}
+            x = {g: ft[sl[1][g].in_nodes.long()] for g in range(2)}
             out = model.forward_parts(sl, x)
             loss = 0
             for g in range(2):
-                seeds = sl[0][g].out_nodes[sl[0][g].owned_out_nodes]
+                seeds = sl[0][g].out_nodes[sl[0][g].owned_out_nodes.long()].long()
                 loss = loss + torch.nn.functional.cross_entropy(out[g], lt[seeds], reduction="sum")
             loss = loss / 128
             opt.zero_grad()
