@@ -354,6 +354,39 @@ def main():
                 "iters_per_sec": nb / secT,
                 "single_thread": {"value": e1 / sec1, "iters_per_sec": 2 / sec1, "sample": "2 minibatches"},
             }
+            # the UNMODIFIED reference (oracle/_ref/ref_harness, built from /root/reference in the build
+            # container) at its hard-coded constants (fanout 10/10/10, 4 parts), beside the port on the
+            # same minibatches: how conservative the "port" baseline is on THIS host
+            harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+            if os.path.exists(harness):
+                try:
+                    import re
+                    import subprocess
+                    from cslicer import l0
+                    d = os.path.join(os.environ.get("CSLICER_BENCH_CACHE", "/tmp/cslicer_bench_cache"),
+                                     "l0_n%d_d%g_s%d" % (args.nodes, args.mean_deg, args.graph_seed))
+                    if not os.path.exists(os.path.join(d, "meta.txt")):
+                        l0.write_l0(d, indptr, indices)
+                    nb_ref = 4 * cores
+                    batches = [perm[i * B:(i + 1) * B] for i in range(nb_ref)]
+                    words = [nb_ref]
+                    for b_ in batches:
+                        words.append(len(b_))
+                        words.extend(int(x) for x in b_)
+                    bp = os.path.join(d, "bench_batches.bin")
+                    np.array(words, dtype=np.int64).tofile(bp)
+                    r = subprocess.run([harness, "bench", d, bp, str(cores)], capture_output=True, text=True,
+                                       timeout=300)
+                    ref_s = float(re.search(r"seconds=([0-9.]+)", r.stderr).group(1))
+                    port_s, port_e = orc.bench(indptr, indices, batches, n_parts=4, fanouts=(10, 10, 10), threads=cores)
+                    out["cpu_baseline"]["reference_calibration"] = {
+                        "kind": "reference", "config": "fanout 10/10/10, 4 parts (the reference's constants), "
+                        "%d minibatches of %d, %d threads" % (nb_ref, B, cores),
+                        "reference_iters_per_sec": nb_ref / ref_s, "reference_edges_per_sec": port_e / ref_s,
+                        "port_iters_per_sec": nb_ref / port_s, "port_over_reference": ref_s / port_s,
+                    }
+                except Exception as ex:  # the calibration is optional evidence, never fatal
+                    out["cpu_baseline"]["reference_calibration"] = {"error": repr(ex)[:200]}
         print(json.dumps(out))
     if eng is not None:
         eng.close()

@@ -931,8 +931,10 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       uint32_t p = s_run[1 + g] + rE;
       for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][1 + g];
       p += TB(K_IN(P, g));  // local index inside slice g's in_nodes
+#ifndef CSL_ABLATE_EMIT_IN
       ar[a.list_base[CSL_IN_NODES] + m.off[CSL_IN_NODES][g] + p] = (int)val;
       a.crank[cbase + k] = p;  // DuplicateRemover::replace's lookup value (mask[v]-1)
+#endif
     }
     __syncthreads();
     if (n < 1 + P) {
@@ -982,6 +984,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
     }
   }
   __syncthreads();
+#ifndef CSL_ABLATE_EMIT_NODES
   if (act) {
     int outrank_to = -1;
 #pragma unroll
@@ -1022,6 +1025,9 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       ar[a.list_base[CSL_TO_IDS] + m.off[CSL_TO_IDS][to] + q] = outrank_to;
     }
   }
+#else
+  if (act) a.selfpos[s * a.fcap + i] = 0;
+#endif
 #undef TB
 }
 
