@@ -123,6 +123,8 @@ class DistSageConv(nn.Module):
         neigh = aggr.GatherRows.apply(agg, sl.owned_out_nodes)
         neigh = neigh / sl.owned_degree.clamp(min=1).to(neigh.dtype).unsqueeze(1)
         self_h = aggr.GatherRows.apply(x, sl.self_ids_in)
+        # (splitting the Linear into two addmm over weight column blocks to avoid this concat was
+        # measured 1.5x slower end to end: strided GEMM operands)
         return self.fc(torch.cat([self_h, neigh], dim=1))
 
 
