@@ -1,0 +1,164 @@
+"""Long-run and edge-case behaviour of the HIP engine against the oracle: mt19937 ring
+wrap-around and host/device position resync, randomised configurations, degenerate inputs,
+capacity errors.  Bit-exact throughout."""
+import numpy as np
+import pytest
+
+from golden_util import assert_same_sample
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def abi():
+    from cslicer import _abi
+    _abi.load()
+    return _abi
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def test_rng_ring_wraps_many_rounds(abi, orc):
+    """A 2^16-word mt19937 window and ~120 rounds: every stream's position passes the window size
+    several times; the generator must stay ahead without overwriting words still to be read."""
+    from cslicer import l0
+    n, B, S = 4000, 64, 3
+    indptr, indices = l0.synth_graph(n, 40.0, seed=17)     # most rows draw (deg >= fanout)
+    perm = np.random.default_rng(8).permutation(n)
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 10), max_batch=B, n_streams=S, n_slots=2,
+                   rng_ring_log2=16)
+    e.set_nodes(perm)
+    oracles = [orc.Oracle(indptr, indices, n_parts=4, fanouts=(10, 10)) for _ in range(S)]
+    rounds_per_epoch = (n // B) // S
+    total_draws = 0
+    for r in range(120):
+        first = (r % rounds_per_epoch) * S
+        e.submit_round(first, B, S, slot=r & 1)
+        want = [oracles[s].sample(perm[(first + s) * B:(first + s + 1) * B]) for s in range(S)]
+        if r % 17 == 0 or r == 119:      # most rounds are NOT fetched: host bounds drift, then resync
+            for s in range(S):
+                got = e.sample_dict(s, slot=r & 1)
+                assert_same_sample(got, want[s], what="round %d stream %d" % (r, s), check_traversal=False)
+                assert got["draws_total"] == want[s]["draws_total"]
+                total_draws = max(total_draws, got["draws_total"])
+    assert total_draws > 4 * (1 << 16), "the test must actually wrap the ring (%d draws)" % total_draws
+    e.close()
+
+
+def test_ring_too_small_is_reported(abi):
+    from cslicer import l0
+    indptr, indices = l0.synth_graph(2000, 30.0, seed=1)
+    with pytest.raises(abi.CslError) as ei:
+        abi.Engine(indptr, indices, fanouts=(15, 10, 5), max_batch=1024, rng_ring_log2=12)
+    assert "rng_ring_log2" in str(ei.value)
+
+
+def test_frontier_capacity_overflow_is_flagged(abi):
+    from cslicer import l0
+    indptr, indices = l0.synth_graph(5000, 30.0, seed=2)
+    e = abi.Engine(indptr, indices, fanouts=(10, 10), max_batch=64, frontier_cap=[0, 100, 0])
+    e.submit_seeds([np.arange(64)])
+    with pytest.raises(abi.CslError) as ei:
+        e.meta(0)
+    assert int(str(ei.value).split("bits ")[1].split()[0], 16) & 8
+    e.close()
+
+
+def test_degenerate_graphs(abi, orc):
+    cases = []
+    # single node, no edges
+    cases.append((np.array([0, 0]), np.zeros(0, dtype=np.int64), [[0]], (10, 10, 10), 4))
+    # two nodes pointing at each other, batch of both
+    cases.append((np.array([0, 1, 2]), np.array([1, 0]), [[1, 0]], (10, 10, 10), 4))
+    # a star whose centre has degree exactly the fanout, fanout 1 elsewhere
+    n = 12
+    rows = [[i for i in range(1, 11)]] + [[0] for _ in range(1, n)]
+    ip = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in rows], out=ip[1:])
+    cases.append((ip, np.concatenate(rows), [[0, 5], [11]], (10, 1), 3))
+    # only self loops
+    cases.append((np.arange(6), np.arange(5), [[0, 1, 2, 3, 4]], (3, 3), 2))
+    for indptr, indices, batches, fan, P in cases:
+        indptr = np.asarray(indptr, dtype=np.int64)
+        indices = np.asarray(indices, dtype=np.int64)
+        e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=8)
+        eg = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=8, mode=abi.MODE_GRAPH)
+        o, og = orc.Oracle(indptr, indices, n_parts=P, fanouts=fan), orc.Oracle(indptr, indices, n_parts=P, fanouts=fan)
+        for b in batches:
+            e.submit_seeds([b])
+            assert_same_sample(e.sample_dict(0), o.sample(np.array(b)), what=str((indptr.tolist(), b)))
+            eg.submit_seeds([b])
+            got, want = eg.graph_dict(0), og.sample_graph(np.array(b))
+            for l in range(len(fan)):
+                for g in range(P):
+                    for k in ("in_nodes", "out_nodes", "indptr", "indices", "owned_out_nodes", "self_ids_in",
+                              "owned_degree"):
+                        np.testing.assert_array_equal(got["layers"][l][g][k], want["layers"][l][g][k])
+        e.close()
+        eg.close()
+
+
+def test_empty_round_and_empty_streams(abi):
+    from cslicer import l0
+    indptr, indices = l0.synth_graph(500, 8.0, seed=3)
+    e = abi.Engine(indptr, indices, max_batch=32, n_streams=4)
+    e.set_nodes(np.arange(40))          # two minibatches only: 32 + 8
+    e.submit_round(0, 32, 4)            # streams 2 and 3 get nothing
+    assert e.meta(0).n_seeds == 32 and e.meta(1).n_seeds == 8
+    for s in (2, 3):
+        m = e.meta(s)
+        assert m.n_seeds == 0 and m.rng_begin == m.rng_end == 0
+        d = e.sample_dict(s)
+        assert all(len(d["layers"][l][g]["in_nodes"]) == 0 for l in range(3) for g in range(4))
+    e.submit_round(5, 32, 0)            # a round with no minibatch at all
+    assert e.meta(0).n_seeds == 0
+    e.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomised_configurations(abi, orc, seed):
+    """Random graph shape, fanouts (incl. 1 and > 16), parts, batch, streams, workload table."""
+    from cslicer import l0
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(50, 6000))
+    deg = float(rng.choice([0.7, 3.0, 12.0, 40.0]))
+    P = int(rng.integers(1, 9))
+    L = int(rng.integers(1, 5))
+    fan = tuple(int(x) for x in rng.choice([1, 2, 5, 10, 15, 20, 33], size=L))
+    B = int(rng.integers(1, min(n, 300) + 1))
+    S = int(rng.integers(1, 4))
+    indptr, indices = l0.synth_graph(n, deg, seed=seed)
+    wl = rng.integers(0, P, size=n).astype(np.int32) if rng.random() < 0.5 else None
+    perm = rng.permutation(n)
+    mode_graph = bool(rng.random() < 0.4)
+    e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2, workload=wl,
+                   mode=abi.MODE_GRAPH if mode_graph else abi.MODE_STRICT)
+    e.set_nodes(perm)
+    oracles = [orc.Oracle(indptr, indices, n_parts=P, fanouts=fan, workload=wl) for _ in range(S)]
+    nb = (n + B - 1) // B
+    for r in range(min(3, (nb + S - 1) // S)):
+        k = min(S, nb - r * S)
+        e.submit_round(r * S, B, k, slot=r & 1)
+        for s in range(k):
+            seeds = perm[(r * S + s) * B:(r * S + s + 1) * B]
+            tag = "seed %d cfg n=%d deg=%g P=%d fan=%s B=%d S=%d round %d stream %d" % (seed, n, deg, P, fan, B, S, r, s)
+            if mode_graph:
+                got, want = e.graph_dict(s, slot=r & 1), oracles[s].sample_graph(seeds)
+                for l in range(L):
+                    for g in range(P):
+                        for key in ("in_nodes", "out_nodes", "indptr", "indices", "owned_out_nodes", "self_ids_in",
+                                    "self_ids_out", "owned_degree"):
+                            np.testing.assert_array_equal(got["layers"][l][g][key], want["layers"][l][g][key],
+                                                          err_msg=tag + " " + key)
+                        for p in range(P):
+                            np.testing.assert_array_equal(got["layers"][l][g]["from_ids"][p],
+                                                          want["layers"][l][g]["from_ids"][p], err_msg=tag)
+                            np.testing.assert_array_equal(got["layers"][l][g]["to_ids"][p],
+                                                          want["layers"][l][g]["to_ids"][p], err_msg=tag)
+            else:
+                assert_same_sample(e.sample_dict(s, slot=r & 1), oracles[s].sample(seeds), what=tag)
+    e.close()
