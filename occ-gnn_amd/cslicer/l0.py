@@ -152,3 +152,70 @@ def read_l0(path, mmap=True, check=True):
         if int(np.sum(indices, dtype=np.int64)) != meta["csum_edges"]:
             raise ValueError("indices checksum mismatch in %s" % path)
     return indptr, indices, meta
+
+
+def from_edge_list(num_nodes, src, dst, symmetric=False, rows="in"):
+    """Edge list -> L0 CSR the way the reference converter prepares it
+    (python/utils/convert_dgl_dataset.py:42-49): self loops removed (:45), rows sorted (:47),
+    duplicate edges kept.  rows="in": row v lists the sources of edges u -> v (what a GNN samples
+    from); rows="out": row u lists the destinations.  The reference takes DGL's `adj()`, whose
+    orientation changed between DGL versions; for the symmetric OGB graphs it converts both are the
+    same matrix.  symmetric=True adds the reverse of every edge first."""
+    src = np.asarray(src, dtype=np.int64).reshape(-1)
+    dst = np.asarray(dst, dtype=np.int64).reshape(-1)
+    if src.shape != dst.shape:
+        raise ValueError("src and dst differ in length")
+    if src.size and (min(src.min(), dst.min()) < 0 or max(src.max(), dst.max()) >= num_nodes):
+        raise ValueError("edge endpoint outside [0, num_nodes)")
+    if symmetric:
+        src, dst = np.concatenate([src, dst]), np.concatenate([dst, src])
+    keep = src != dst                                   # convert_dgl_dataset.py:45
+    src, dst = src[keep], dst[keep]
+    if rows == "out":
+        src, dst = dst, src
+    elif rows != "in":
+        raise ValueError("rows must be 'in' or 'out'")
+    key = dst * np.int64(num_nodes) + src               # group by destination, sort sources in a row
+    key.sort()
+    rows, cols = key // np.int64(num_nodes), key % np.int64(num_nodes)
+    indptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows, minlength=num_nodes), out=indptr[1:])
+    return indptr, cols
+
+
+def _main(argv):
+    """python -m cslicer.l0 convert <edges.npz|edges.npy> <out_dir> [--symmetric] [--num-nodes N]
+    edges.npz: arrays `src`, `dst` (optionally `features`, `labels`, `partition`, `num_nodes`);
+    edges.npy: int array of shape [2, E] or [E, 2]."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="cslicer.l0")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    c = sub.add_parser("convert")
+    c.add_argument("edges")
+    c.add_argument("out_dir")
+    c.add_argument("--symmetric", action="store_true")
+    c.add_argument("--num-nodes", type=int, default=None)
+    a = ap.parse_args(argv)
+    feats = labels = part = None
+    if a.edges.endswith(".npz"):
+        z = np.load(a.edges)                              # allow_pickle stays False
+        src, dst = z["src"], z["dst"]
+        feats = z["features"] if "features" in z.files else None
+        labels = z["labels"] if "labels" in z.files else None
+        part = z["partition"] if "partition" in z.files else None
+        n = a.num_nodes or (int(z["num_nodes"]) if "num_nodes" in z.files else None)
+    else:
+        e = np.load(a.edges)
+        e = e if e.shape[0] == 2 else e.T
+        src, dst, n = e[0], e[1], a.num_nodes
+    if n is None:
+        n = int(max(src.max(), dst.max())) + 1
+    indptr, indices = from_edge_list(n, src, dst, symmetric=a.symmetric)
+    classes = int(labels.max()) + 1 if labels is not None else 2
+    meta = write_l0(a.out_dir, indptr, indices, features=feats, labels=labels, partition=part, num_classes=classes)
+    print("wrote %s: %s" % (a.out_dir, meta))
+
+
+if __name__ == "__main__":
+    import sys
+    _main(sys.argv[1:])

@@ -5,6 +5,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -124,3 +125,25 @@ def test_native_module_missing_dataset_raises(tmp_path):
     import pytest
     with pytest.raises(RuntimeError):
         m.cslicer("nope", 16, 2, 1, 64, data_root=str(tmp_path))
+
+
+def test_l0_converter_from_edge_list(tmp_path):
+    # counterpart of python/utils/convert_dgl_dataset.py:42-49: in-neighbour CSR, no self loops, rows sorted
+    from cslicer import l0
+    src = np.array([0, 1, 2, 2, 3, 3, 1, 4])
+    dst = np.array([1, 2, 2, 0, 0, 1, 2, 4])          # (2,2) and (4,4) are self loops
+    indptr, indices = l0.from_edge_list(5, src, dst)
+    assert indptr.tolist() == [0, 2, 4, 6, 6, 6]
+    assert indices.tolist() == [2, 3, 0, 3, 1, 1]       # duplicates (1->2 twice) kept, rows sorted
+    ip2, ix2 = l0.from_edge_list(5, src, dst, symmetric=True)
+    assert ip2[-1] == 2 * 6 and (np.diff(ip2) >= 0).all()
+    np.savez(tmp_path / "e.npz", src=src, dst=dst, num_nodes=np.int64(5))
+    import subprocess
+    r = subprocess.run([sys.executable, "-m", "cslicer.l0", "convert", str(tmp_path / "e.npz"), str(tmp_path / "out")],
+                       env=dict(os.environ, PYTHONPATH=os.path.join(ROOT, "occ-gnn_amd")), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    a, b, m = l0.read_l0(str(tmp_path / "out"), mmap=False)
+    np.testing.assert_array_equal(a, indptr)
+    np.testing.assert_array_equal(b, indices)
+    with pytest.raises(ValueError):
+        l0.from_edge_list(3, [0, 5], [1, 2])
