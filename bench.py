@@ -191,7 +191,9 @@ def main():
     for w in range(args.warmup):
         run_round(w)
     eng.sync()
+    edges0, iters0 = eng.totals()        # device-side running totals: exact units of the timed region
     dt = shard.max_over_ranks(timed(args.steps, args.warmup), dist, red_dev)
+    edges1, iters1 = eng.totals()
 
     # ---- units processed: read the last two rounds' metas (both slots)
     def slot_stats(slot):
@@ -215,8 +217,8 @@ def main():
 
     stats = slot_stats((args.warmup + args.steps - 1) & 1)
     edges_per_round = sum(d["E"] for d in stats)
-    total_edges = shard.sum_over_ranks(edges_per_round * args.steps, dist, red_dev)
-    iters = args.steps * S * world
+    total_edges = shard.sum_over_ranks(edges1 - edges0, dist, red_dev)
+    iters = int(shard.sum_over_ranks(iters1 - iters0, dist, red_dev))
     value = total_edges / dt
 
     out = {

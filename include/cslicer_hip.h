@@ -217,6 +217,10 @@ const char* csl_kernel_name(int32_t k);
 /* device mt19937 stream self-test hook: copies words [pos, pos+n) to dst */
 int csl_rng_peek(csl_engine* e, uint64_t pos, uint32_t* dst, int64_t n);
 
+/* totals since csl_create over all streams (waits for submitted rounds): sampled edges
+ * (neighbour_sample entries without the leading self entry) and minibatches sliced */
+int csl_totals(csl_engine* e, uint64_t* sampled_edges, uint64_t* minibatches);
+
 /* device memory the engine holds, bytes */
 int64_t csl_device_bytes(csl_engine* e);
 

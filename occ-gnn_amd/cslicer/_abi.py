@@ -33,7 +33,7 @@ SYMBOLS = [
     "csl_submit_round", "csl_submit_seeds", "csl_sync", "csl_get_meta", "csl_copy_list",
     "csl_list_device_ptr", "csl_frontier_device_ptr", "csl_copy_frontier", "csl_hip_stream",
     "csl_timing_enable", "csl_timing_read", "csl_kernel_name", "csl_rng_peek", "csl_device_bytes",
-    "csl_fetch_sample",
+    "csl_fetch_sample", "csl_totals",
 ]
 
 
@@ -126,6 +126,7 @@ def load():
     L.csl_kernel_name.argtypes = [C.c_int32]
     L.csl_kernel_name.restype = C.c_char_p
     L.csl_rng_peek.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32), C.c_int64]
+    L.csl_totals.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.csl_device_bytes.argtypes = [vp]
     L.csl_device_bytes.restype = C.c_int64
     if L.csl_abi_version() != ABI_VERSION:
@@ -349,6 +350,12 @@ class Engine:
         out = np.empty(n, dtype=np.uint32)
         _check(load().csl_rng_peek(self._h, pos, out.ctypes.data_as(C.POINTER(C.c_uint32)), n))
         return out
+
+    def totals(self):
+        """(sampled edges, minibatches) sliced since creation, all streams; waits for submitted rounds."""
+        ed, mb = C.c_uint64(0), C.c_uint64(0)
+        _check(load().csl_totals(self._h, C.byref(ed), C.byref(mb)))
+        return int(ed.value), int(mb.value)
 
     def device_bytes(self):
         return int(load().csl_device_bytes(self._h))

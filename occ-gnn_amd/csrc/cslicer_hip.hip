@@ -106,6 +106,7 @@ struct LArgs {
   unsigned long long ring_mask, gen_lo, gen_hi;
   unsigned long long* rngpos;   // [S] running position
   unsigned long long* rngbase;  // [S] base of the current layer
+  unsigned long long* acc;      // [S][2] running totals since creation: sampled edges, minibatches
   // per-stream scratch (stride = elements per stream)
   const uint32_t* fr_in;        // [S][fr_in_stride]
   uint32_t* fr_out;             // [S][fr_out_stride]
@@ -304,6 +305,8 @@ __global__ __launch_bounds__(TN) void k_scan(LArgs a) {
       a.rngpos[s] = base + draws;
       if (a.layer == 0) a.meta[s].rng_begin = base;
       a.meta[s].rng_end = base + draws;
+      a.acc[2 * s] += s_tot[K_EDGES];
+      if (a.layer == 0 && F) a.acc[2 * s + 1] += 1;
       m.frontier = F;
       m.draws = (uint32_t)draws;
       m.sampled_edges = s_tot[K_EDGES];
@@ -1254,6 +1257,8 @@ struct csl_engine {
   bool chain_valid = false;
   std::vector<hipEvent_t> slot_event;  // recorded after the round that fills a result slot
   std::vector<char> slot_pending;
+  std::vector<hipEvent_t> desc_event;  // recorded after a slot's batch descriptors were uploaded
+  std::vector<char> desc_inflight;
   // graph
   unsigned long long* rowinfo = nullptr;
   uint32_t* indices = nullptr;
@@ -1269,6 +1274,7 @@ struct csl_engine {
   uint64_t ring_words = 0, gen_hi = 0;
   unsigned long long* rngpos = nullptr;
   unsigned long long* rngbase = nullptr;
+  unsigned long long* acc = nullptr;
   std::vector<uint64_t> pos_ub, pos_lb;
   uint64_t worst_draws = 0;
   // capacities
@@ -1462,6 +1468,8 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
   const unsigned long long gen_lo = e->gen_hi > e->ring_words ? e->gen_hi - e->ring_words : 0;
   BatchDesc* dd = e->desc_dev + (size_t)slot * S;
   HIPCHECK(hipMemcpyAsync(dd, e->desc_host + (size_t)slot * S, sizeof(BatchDesc) * S, hipMemcpyHostToDevice, st));
+  HIPCHECK(hipEventRecord(e->desc_event[slot], st));
+  e->desc_inflight[slot] = 1;
   csl_sample_meta* meta = e->meta + (size_t)slot * S;
   {
     Timed t(e, KN_SEEDS, st);
@@ -1483,6 +1491,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.gen_hi = e->gen_hi;
     a.rngpos = e->rngpos;
     a.rngbase = e->rngbase + (size_t)set * S;
+    a.acc = e->acc;
     a.fr_in = e->fr[l] + (size_t)slot * S * e->fcap[l];
     a.fr_out = e->fr[l + 1] + (size_t)slot * S * e->fcap[l + 1];
     a.fr_in_stride = e->fcap[l];
@@ -1616,7 +1625,7 @@ void csl_destroy(csl_engine* e) {
   void* ptrs[] = {e->rowinfo, e->indices, e->wl,      e->nodes, e->seedbuf, e->ring,  e->mt_state, e->rngpos,
                   e->rngbase, e->ninfo,   e->hasedge, e->selfpos, e->firstpos, e->cand, e->cflag, e->crank,
                   e->queue,   e->nbk,     e->bcnt,    e->bcur,    e->tcnt,     e->fsize, e->meta, e->desc_dev,
-                  e->ecnt,    e->srcpos};
+                  e->ecnt,    e->srcpos,  e->acc};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (int l = 0; l <= CSL_MAX_LAYERS; l++)
@@ -1630,6 +1639,7 @@ void csl_destroy(csl_engine* e) {
   if (e->rng_event) hipEventDestroy(e->rng_event);
   if (e->chain_event) hipEventDestroy(e->chain_event);
   for (auto ev : e->slot_event) hipEventDestroy(ev);
+  for (auto ev : e->desc_event) hipEventDestroy(ev);
   for (int k = 0; k < 2; k++)
     if (e->streams[k]) hipStreamDestroy(e->streams[k]);
   if (e->rng_stream) hipStreamDestroy(e->rng_stream);
@@ -1732,6 +1742,8 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   DMALLOC(e->fsize, e->nsets * (size_t)S * (CSL_MAX_LAYERS + 1));
   DMALLOC(e->rngpos, (size_t)S);
   DMALLOC(e->rngbase, e->nsets * (size_t)S);
+  DMALLOC(e->acc, (size_t)2 * S);
+  HIPCHECK(hipMemsetAsync(e->acc, 0, sizeof(unsigned long long) * 2 * S, e->stream));
   HIPCHECK(hipMemsetAsync(e->rngpos, 0, sizeof(unsigned long long) * S, e->stream));
   HIPCHECK(hipMemsetAsync(e->fsize, 0, sizeof(uint32_t) * e->nsets * S * (CSL_MAX_LAYERS + 1), e->stream));
   // ---- result arenas
@@ -1778,7 +1790,12 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   e->meta_valid.assign(e->slots, 0);
   e->slot_event.resize(e->slots);
   e->slot_pending.assign(e->slots, 0);
-  for (int k = 0; k < e->slots; k++) HIPCHECK(hipEventCreateWithFlags(&e->slot_event[k], hipEventDisableTiming));
+  e->desc_event.resize(e->slots);
+  e->desc_inflight.assign(e->slots, 0);
+  for (int k = 0; k < e->slots; k++) {
+    HIPCHECK(hipEventCreateWithFlags(&e->slot_event[k], hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&e->desc_event[k], hipEventDisableTiming));
+  }
   // ---- rng
   const uint32_t lg = cfg->rng_ring_log2 ? cfg->rng_ring_log2 : 26;
   e->ring_words = 1ull << lg;
@@ -1869,6 +1886,12 @@ int csl_submit_round(csl_engine* e, int64_t first_batch, int32_t batch_size, int
   if (batch_size < 1 || batch_size > e->cfg.max_batch) return fail(CSL_E_INVALID, "batch_size must be 1..max_batch");
   if (first_batch < 0) return fail(CSL_E_INVALID, "first_batch < 0");
   HIPCHECK(hipSetDevice(e->cfg.device));
+  // the pinned descriptor block of this slot is read when the earlier round's copy EXECUTES, not when
+  // it was enqueued: a host running ahead must not overwrite it before then
+  if (e->desc_inflight[slot]) {
+    HIPCHECK(hipEventSynchronize(e->desc_event[slot]));
+    e->desc_inflight[slot] = 0;
+  }
   BatchDesc* d = e->desc_host + (size_t)slot * e->S;
   for (int s = 0; s < e->S; s++) {
     long long off = (first_batch + s) * (long long)batch_size;
@@ -1888,6 +1911,10 @@ int csl_submit_seeds(csl_engine* e, const int64_t* seeds, const int64_t* offsets
   HIPCHECK(hipSetDevice(e->cfg.device));
   const int64_t total = offsets[n_batches] - offsets[0];
   if (total < 0) return fail(CSL_E_INVALID, "offsets not ascending");
+  if (e->desc_inflight[slot]) {
+    HIPCHECK(hipEventSynchronize(e->desc_event[slot]));
+    e->desc_inflight[slot] = 0;
+  }
   BatchDesc* d = e->desc_host + (size_t)slot * e->S;
   for (int s = 0; s < e->S; s++) {
     d[s].offset = 0;
@@ -2109,5 +2136,21 @@ int csl_rng_peek(csl_engine* e, uint64_t pos, uint32_t* dst, int64_t n) {
 }
 
 int64_t csl_device_bytes(csl_engine* e) { return e ? e->dev_bytes : 0; }
+
+int csl_totals(csl_engine* e, uint64_t* sampled_edges, uint64_t* minibatches) {
+  if (!e) return fail(CSL_E_INVALID, "null engine");
+  int r = csl_sync(e);
+  if (r) return r;
+  std::vector<unsigned long long> tmp((size_t)2 * e->S);
+  HIPCHECK(hipMemcpy(tmp.data(), e->acc, sizeof(unsigned long long) * tmp.size(), hipMemcpyDeviceToHost));
+  uint64_t ed = 0, mb = 0;
+  for (int s = 0; s < e->S; s++) {
+    ed += tmp[2 * s];
+    mb += tmp[2 * s + 1];
+  }
+  if (sampled_edges) *sampled_edges = ed;
+  if (minibatches) *minibatches = mb;
+  return 0;
+}
 
 }  // extern "C"

@@ -162,3 +162,20 @@ def test_randomised_configurations(abi, orc, seed):
             else:
                 assert_same_sample(e.sample_dict(s, slot=r & 1), oracles[s].sample(seeds), what=tag)
     e.close()
+
+
+def test_running_totals_are_exact(abi, orc):
+    from cslicer import l0
+    indptr, indices = l0.synth_graph(3000, 18.0, seed=6)
+    perm = np.random.default_rng(2).permutation(3000)
+    e = abi.Engine(indptr, indices, fanouts=(10, 5), max_batch=100, n_streams=3, n_slots=2)
+    e.set_nodes(perm)
+    assert e.totals() == (0, 0)
+    want_edges = 0
+    oracles = [orc.Oracle(indptr, indices, fanouts=(10, 5)) for _ in range(3)]
+    for r in range(4):
+        e.submit_round(r * 3, 100, 3, slot=r & 1)
+        for s in range(3):
+            want_edges += oracles[s].sample(perm[(r * 3 + s) * 100:(r * 3 + s + 1) * 100])["sampled_edges"]
+    assert e.totals() == (want_edges, 12)
+    e.close()
