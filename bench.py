@@ -356,6 +356,8 @@ def main():
                 "iters_per_sec": nb / secT,
                 "single_thread": {"value": e1 / sec1, "iters_per_sec": 2 / sec1, "sample": "2 minibatches"},
             }
+            secN, eN = orc.bench(indptr, indices, sample, n_parts=P, fanouts=fan, threads=cores, deep_copy=False)
+            out["cpu_baseline"]["without_deep_copy"] = {"value": eN / secN, "iters_per_sec": nb / secN}
             # the UNMODIFIED reference (oracle/_ref/ref_harness, built from /root/reference in the build
             # container) at its hard-coded constants (fanout 10/10/10, 4 parts), beside the port on the
             # same minibatches: how conservative the "port" baseline is on THIS host

@@ -116,3 +116,17 @@ def test_two_ranks_match_single_process_two_parts(overlap):
     for rank, losses, w in res:
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(w, w_ref, rtol=1e-4, atol=1e-5)
+
+
+def test_batch_slice_script_prints_exp5_keys(capsys):
+    """cslicer.batch_slice (counterpart of python/batch_slice_multi_gpu.py): the four lines
+    experiments/exp5/populate_table.py:22-25 parses must match its regexes."""
+    import re
+    from cslicer import batch_slice
+    batch_slice.main(["--nodes", "20000", "--mean-deg", "10", "--fsize", "16", "--batch-size", "1024",
+                      "--fan-out", "10,10", "--num-epochs", "2", "--streams", "4"])
+    out = capsys.readouterr().out
+    for pat in (r"forward_time_per_epoch:(\d+\.\d+)", r"merge_time per epoch:(\d+\.\d+)",
+                r"data transfer:(\d+\.\d+)", r"graph splitting time:(\d+\.\d+)"):
+        m = re.findall(pat, out)
+        assert len(m) == 1 and float(m[0]) >= 0.0, (pat, out)
