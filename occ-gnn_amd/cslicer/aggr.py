@@ -154,3 +154,22 @@ class ScatterAddRows(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         g = g.contiguous()
         return g, None, gather_rows(g, idx)
+
+
+class GatherMeanRows(torch.autograd.Function):
+    """dst[k] = src[idx[k]] / max(deg[k], 1): slice_owned_nodes + mean normalisation in two HIP
+    launches (row gather, in-place degree division) instead of a chain of elementwise torch ops."""
+
+    @staticmethod
+    def forward(ctx, src, idx, deg):
+        ctx.save_for_backward(idx, deg)
+        ctx.n_src = src.shape[0]
+        return div_rows_(gather_rows(src, idx), deg)
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, deg = ctx.saved_tensors
+        g = div_rows_(g.contiguous().clone(), deg)
+        gs = torch.zeros((ctx.n_src, g.shape[1]), dtype=torch.float32, device=g.device)
+        scatter_add_rows_(gs, idx, g)
+        return gs, None, None
