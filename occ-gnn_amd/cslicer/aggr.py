@@ -173,3 +173,10 @@ class GatherMeanRows(torch.autograd.Function):
         gs = torch.zeros((ctx.n_src, g.shape[1]), dtype=torch.float32, device=g.device)
         scatter_add_rows_(gs, idx, g)
         return gs, None, None
+
+
+def attention_gather(indptr, indices, u_in, v_in, n_rows):
+    """BipartiteGraph.attention_gather (python/data/bipartite.py:75-80): out[v] = sum over in-edges
+    (u, v) of u_in[u] * v_in[v] (DGL u_mul_v + sum).  v_in[v] does not depend on u, so this is the
+    sum-aggregate scaled row-wise: one SpMM launch plus an elementwise product."""
+    return SpmmSum.apply(u_in, indptr, indices, n_rows) * v_in

@@ -83,6 +83,21 @@ def test_gather_scatter_div_rows(mods, H):
     torch.testing.assert_close(s.grad.cpu(), gref, rtol=0, atol=0)
 
 
+def test_attention_gather_matches_u_mul_v_sum(mods):
+    _, aggr, _ = mods
+    rng = np.random.default_rng(5)
+    n_rows, n_src, H = 300, 200, 24
+    indptr, indices = _rand_csr(n_rows, n_src, 9, rng)
+    u, v = torch.randn(n_src, H), torch.randn(n_rows, H)
+    ref = torch.zeros(n_rows, H)
+    for r in range(n_rows):
+        for e in range(indptr[r], indptr[r + 1]):
+            ref[r] += u[indices[e]] * v[r]
+    got = aggr.attention_gather(torch.from_numpy(indptr).int().cuda(), torch.from_numpy(indices).int().cuda(),
+                                u.cuda(), v.cuda(), n_rows)
+    torch.testing.assert_close(got.cpu(), ref, **TOL)
+
+
 def _dense_reference(model, indptr, indices, trav, feats, P):
     """Unsplit torch fp32 GraphSAGE on the same sampled computation graph (CPU)."""
     L = len(trav["nbr_counts"])
