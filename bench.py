@@ -244,6 +244,7 @@ def main():
             "round_overlap": not args.serial_rounds,
             "device_lists": "int32 (host exports widen to the reference's int64)",
             "sampled_edges_per_minibatch": edges_per_round / S,
+            "engine_device_bytes": eng.device_bytes(),
         },
     }
 

@@ -21,7 +21,10 @@
  * table (csl_layer_meta).  csl_copy_list / csl_list_device_ptr hand them out.
  *
  * All functions return 0 on success, a negative CSL_E_* code on failure;
- * csl_last_error() gives the message.  Nothing here falls back to a CPU path.
+ * csl_last_error() gives the message (per calling thread).  Nothing here falls
+ * back to a CPU path.  An engine is driven by one thread at a time (the
+ * reference's CSlicer is likewise single-consumer); different engines are
+ * independent.
  */
 #ifndef CSLICER_HIP_H
 #define CSLICER_HIP_H
