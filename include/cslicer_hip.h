@@ -192,6 +192,12 @@ int64_t csl_copy_list(csl_engine* e, int32_t slot, int32_t stream, int32_t layer
 int csl_fetch_sample(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta,
                      const int64_t** host_ptr, int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS]);
 
+/* Same batch of copies without the widening pass: *host_ptr is the pinned int32 staging
+ * buffer itself (valid until the next fetch); the caller widens while filling its own
+ * `long` vectors. */
+int csl_fetch_sample32(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta,
+                       const int32_t** host_ptr, int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS]);
+
 /* zero-copy surface: device pointer of the kind's array (all parts back to back,
  * offsets in csl_layer_meta.off).  On the device the lists are int32 (ids and local
  * indices are < 2^31, -1 sentinels kept): half the store traffic of the reference's

@@ -2007,9 +2007,9 @@ int64_t csl_copy_list(csl_engine* e, int32_t slot, int32_t stream, int32_t layer
   return n;
 }
 
-int csl_fetch_sample(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta, const int64_t** host_ptr,
-                     int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS]) {
-  if (!e || !meta || !host_ptr || !seg) return fail(CSL_E_INVALID, "null argument");
+static int fetch_stage(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta,
+                       int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS], size_t* total) {
+  if (!e || !meta || !seg) return fail(CSL_E_INVALID, "null argument");
   if (slot < 0 || slot >= e->slots || stream < 0 || stream >= e->S) return fail(CSL_E_INVALID, "slot/stream out of range");
   HIPCHECK(hipSetDevice(e->cfg.device));
   int r = load_meta(e, slot);
@@ -2017,7 +2017,7 @@ int csl_fetch_sample(csl_engine* e, int32_t slot, int32_t stream, csl_sample_met
   const csl_sample_meta& sm = e->meta_host[(size_t)slot * e->S + stream];
   *meta = sm;
   if (sm.error) return fail(CSL_E_DEVICE, "device flagged error bits 0x%x in slot %d stream %d", sm.error, slot, stream);
-  if (!e->fetch_host) {
+  if (!e->fetch_stage) {
     size_t cap = 0;
     for (int l = 0; l < e->L; l++) cap += e->arena_stride[l];
     HIPCHECK(hipHostMalloc((void**)&e->fetch_stage, cap * sizeof(int), hipHostMallocDefault));
@@ -2039,8 +2039,28 @@ int csl_fetch_sample(csl_engine* e, int32_t slot, int32_t stream, csl_sample_met
     }
   }
   HIPCHECK(hipStreamSynchronize(e->copy_stream));
+  *total = o;
+  return 0;
+}
+
+int csl_fetch_sample(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta, const int64_t** host_ptr,
+                     int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS]) {
+  if (!host_ptr) return fail(CSL_E_INVALID, "null argument");
+  size_t o = 0;
+  int r = fetch_stage(e, slot, stream, meta, seg, &o);
+  if (r) return r;
   for (size_t i = 0; i < o; i++) e->fetch_host[i] = (long long)e->fetch_stage[i];  // widen to `long`
   *host_ptr = (const int64_t*)e->fetch_host;
+  return 0;
+}
+
+int csl_fetch_sample32(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta, const int32_t** host_ptr,
+                       int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS]) {
+  if (!host_ptr) return fail(CSL_E_INVALID, "null argument");
+  size_t o = 0;
+  int r = fetch_stage(e, slot, stream, meta, seg, &o);
+  if (r) return r;
+  *host_ptr = (const int32_t*)e->fetch_stage;
   return 0;
 }
 

@@ -265,14 +265,14 @@ class CSlicer {
  private:
   PySample* fetch(int slot, int stream) {
     csl_sample_meta m;
-    const int64_t* host = nullptr;
+    const int32_t* host = nullptr;  // pinned int32 staging: widened while the vectors are filled
     int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS];
-    check(csl_fetch_sample(eng_, slot, stream, &m, &host, seg), "csl_fetch_sample");
+    check(csl_fetch_sample32(eng_, slot, stream, &m, &host, seg), "csl_fetch_sample32");
     PySample* s = empty_sample(n_layers_, n_parts_);
     auto take = [&](int l, int kind, int g, std::vector<long>& dst) {
       const long lo = (long)m.layer[l].off[kind][g], hi = (long)m.layer[l].off[kind][g + 1];
-      const long* src = reinterpret_cast<const long*>(host) + seg[l][kind] + lo;
-      dst.assign(src, src + (hi - lo));
+      const int32_t* src = host + seg[l][kind] + lo;
+      dst.assign(src, src + (hi - lo));  // int32 -> long
     };
     for (int l = 0; l < n_layers_; l++) {
       for (int g = 0; g < n_parts_; g++) {
