@@ -177,6 +177,41 @@ CASES = {
 }
 
 
+def list_hash(a):
+    """64-bit digest of a list's int64 values, order-sensitive (blake2b of the little-endian bytes)."""
+    import hashlib
+    b = np.ascontiguousarray(np.asarray(a, dtype="<i8")).tobytes()
+    return np.frombuffer(hashlib.blake2b(b, digest_size=8).digest(), dtype="<u8")[0]
+
+
+def hashed_case():
+    """A realistic-size case pinned by hashes only (the lists themselves would be megabytes):
+    products-like degrees on 100k nodes, three consecutive minibatches of 1024 from one permutation.
+    The graph is regenerated from its seed by the tests (cslicer.l0.synth_graph is deterministic)."""
+    n, deg, seed = 100_000, 30.0, 77
+    indptr, indices = l0.synth_graph(n, deg, seed=seed)
+    perm = np.random.default_rng(5).permutation(n)
+    batches = [perm[i * 1024:(i + 1) * 1024].tolist() for i in range(3)]
+    out = run_reference(indptr, indices, batches)
+    rec = {"graph": np.array([n, int(deg * 1000), seed], dtype=np.int64),
+           "graph_csum": np.array([int(indptr.sum()), int(indices.sum())], dtype=np.int64),
+           "perm_seed": np.array([5], dtype=np.int64)}
+    names = LISTS + ["from_ids%d" % j for j in range(4)] + ["to_ids%d" % j for j in range(4)]
+    for b in range(3):
+        for l in range(3):
+            k = "b%d_l%d_" % (b, l)
+            rec[k + "next_frontier_hash"] = np.array([list_hash(out[k + "next_frontier"]), len(out[k + "next_frontier"])],
+                                                     dtype=np.uint64)
+            rec[k + "draws"] = out[k + "draws"]
+            for g in range(4):
+                hs = [[list_hash(out[k + "g%d_%s" % (g, nm)]), len(out[k + "g%d_%s" % (g, nm)])] for nm in names]
+                rec[k + "g%d" % g] = np.array(hs, dtype=np.uint64)
+    path = os.path.join(GOLD, "hashed_100k.npz")
+    np.savez_compressed(path, **rec)
+    print("%-24s nodes=%d edges=%d batches=3 -> %s (%d bytes)" % ("hashed_100k", n, indices.shape[0], path,
+                                                                  os.path.getsize(path)))
+
+
 def main():
     if not os.path.exists(HARNESS):
         sys.exit("build oracle/_ref/ref_harness first (make -C oracle ref)")
@@ -197,6 +232,7 @@ def main():
         np.savez_compressed(path, **small)
         print("%-24s nodes=%d edges=%d batches=%d -> %s (%d bytes)" % (
             name, indptr.shape[0] - 1, indices.shape[0], len(batches), path, os.path.getsize(path)))
+    hashed_case()
 
 
 if __name__ == "__main__":

@@ -64,3 +64,43 @@ def assert_same_sample(got, want, what="", check_traversal=True):
                                                   err_msg="%s %s[%d]" % (what, key, l))
         if "draws" in got and "draws" in want:
             assert list(got["draws"]) == list(want["draws"]), what + "draws"
+
+
+def list_hash(a):
+    """Same digest as oracle/make_golden.py::list_hash."""
+    import hashlib
+    b = np.ascontiguousarray(np.asarray(a, dtype="<i8")).tobytes()
+    return int(np.frombuffer(hashlib.blake2b(b, digest_size=8).digest(), dtype="<u8")[0])
+
+
+def load_hashed_case():
+    """tests/golden/hashed_100k.npz: the unmodified reference on a 100k-node products-like graph,
+    3 consecutive minibatches of 1024, every exported list pinned by (digest, length)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "occ-gnn_amd"))
+    from cslicer import l0
+    d = np.load(os.path.join(GOLDEN_DIR, "hashed_100k.npz"))
+    n, deg1000, seed = (int(x) for x in d["graph"])
+    indptr, indices = l0.synth_graph(n, deg1000 / 1000.0, seed=seed)
+    assert [int(indptr.sum()), int(indices.sum())] == [int(x) for x in d["graph_csum"]], "generator drifted"
+    perm = np.random.default_rng(int(d["perm_seed"][0])).permutation(n)
+    batches = [perm[i * 1024:(i + 1) * 1024] for i in range(3)]
+    return indptr, indices, batches, d
+
+
+def assert_matches_hashed(sample, d, b, what=""):
+    names = LIST_NAMES + ["from_ids%d" % j for j in range(4)] + ["to_ids%d" % j for j in range(4)]
+    for l in range(3):
+        for g in range(4):
+            want = d["b%d_l%d_g%d" % (b, l, g)]
+            bp = sample["layers"][l][g]
+            for k, nm in enumerate(names):
+                lst = bp[nm] if nm in bp else bp[nm[:-1]][int(nm[-1])]
+                assert (list_hash(lst), len(lst)) == (int(want[k][0]), int(want[k][1])), \
+                    "%s batch %d layer %d part %d %s" % (what, b, l, g, nm)
+        if "frontier" in sample:
+            nf = d["b%d_l%d_next_frontier_hash" % (b, l)]
+            fr = sample["frontier"][l + 1]
+            assert (list_hash(fr), len(fr)) == (int(nf[0]), int(nf[1])), "%s batch %d next frontier %d" % (what, b, l)
+        if "draws" in sample:
+            assert int(sample["draws"][l]) == int(d["b%d_l%d_draws" % (b, l)][0])

@@ -426,3 +426,15 @@ def test_frontends_use_partition_map_file(orc, tmp_path, monkeypatch):
                 assert s.layers[l][g].self_ids_in == want["layers"][l][g]["self_ids_in"].tolist()
                 assert s.layers[l][g].from_ids[g] == want["layers"][l][g]["from_ids"][g].tolist()
         del csl
+
+
+def test_reference_digest_parity_at_realistic_size(abi):
+    """The HIP engine against the unmodified reference directly (not via the oracle) on a 100k-node
+    graph: digests of every exported list, next frontier and draw counts of 3 consecutive minibatches."""
+    from golden_util import assert_matches_hashed, load_hashed_case
+    indptr, indices, batches, d = load_hashed_case()
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 10, 10), max_batch=1024, n_streams=1)
+    for b, seeds in enumerate(batches):
+        e.submit_seeds([seeds])
+        assert_matches_hashed(e.sample_dict(0), d, b, what="hip")
+    e.close()
