@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--slots", type=int, default=2, help="result slots = rounds in flight (engine streams/scratch sets)")
     ap.add_argument("--serial-rounds", action="store_true",
                     help="no overlap of consecutive rounds (profiling: undisturbed per-kernel durations)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
@@ -165,7 +166,8 @@ def main():
     S, B, P = args.streams, args.batch, args.parts
     perm = np.random.default_rng(1).permutation(N).astype(np.int64)
     eng_flags = _abi.FLAG_SERIAL_ROUNDS if args.serial_rounds else 0
-    eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2,
+    NS = args.slots
+    eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=NS,
                       device=device, flags=eng_flags)
     eng.set_nodes(perm)
     from cslicer import shard
@@ -174,7 +176,7 @@ def main():
     def run_round(step):
         # weak scaling: rank r takes its own rounds (cslicer/shard.py); wraps around the epoch
         first, nb = shard.batches_of_round(shard.round_of(step, rank, world, n_rounds), S)
-        eng.submit_round(first, B, nb, slot=step & 1)
+        eng.submit_round(first, B, nb, slot=step % NS)
 
     def timed(nsteps, first_step):
         barrier()
@@ -215,7 +217,7 @@ def main():
                 d["list_total"] += sum(tot) + tot[_abi.OUT_NODES]  # + indptr ones
         return layers
 
-    stats = slot_stats((args.warmup + args.steps - 1) & 1)
+    stats = slot_stats((args.warmup + args.steps - 1) % NS)
     edges_per_round = sum(d["E"] for d in stats)
     total_edges = shard.sum_over_ranks(edges1 - edges0, dist, red_dev)
     iters = int(shard.sum_over_ranks(iters1 - iters0, dist, red_dev))
@@ -275,7 +277,7 @@ def main():
             "scaling": "strong",
         }
         tr.close()
-        eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2,
+        eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=NS,
                           device=device, flags=eng_flags) if (rank == 0 and not args.no_kernel_timing) else None
         if eng is not None:
             eng.set_nodes(perm)
@@ -294,7 +296,7 @@ def main():
             t_ev = time.perf_counter() - t_ev
             tim = eng.timing_read()
             eng.timing_enable(False)
-            stats2 = slot_stats((args.warmup + 2 * args.steps - 1) & 1)
+            stats2 = slot_stats((args.warmup + 2 * args.steps - 1) % NS)
             per_kernel = {}
             for name, (ms, n) in tim.items():
                 if n == 0 or name in ("k_seeds", "k_scan_need", "k_scan_lists", "k_scan_buckets", "k_mt19937_fill"):

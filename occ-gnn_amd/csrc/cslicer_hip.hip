@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <deque>
 #include <vector>
 
 #include "cslicer_hip.h"
@@ -45,6 +46,7 @@ namespace {
 constexpr uint32_t UNSET = 0xFFFFFFFFu;
 
 constexpr int TN = 256;  // frontier nodes per tile == threads per block
+constexpr int CSL_MAX_SETS = 4;  // rounds in flight at once (HIP streams / scratch sets)
 constexpr int NW = TN / 64;
 // tuning constants (overridable with -D for sweeps; defaults measured best on MI355X, round 1)
 #ifndef CSL_TPB
@@ -1251,7 +1253,7 @@ struct csl_engine {
   // slots): the latency-bound small layers of round r+1 run beside the big last layer of round r.
   // `stream` aliases streams[0].
   hipStream_t stream = nullptr, rng_stream = nullptr;
-  hipStream_t streams[2] = {nullptr, nullptr};
+  hipStream_t streams[CSL_MAX_SETS] = {};
   int nsets = 1;
   hipEvent_t rng_event = nullptr;
   hipEvent_t chain_event = nullptr;  // recorded after a round's last rng-position update
@@ -1278,6 +1280,20 @@ struct csl_engine {
   unsigned long long* acc = nullptr;
   std::vector<uint64_t> pos_ub, pos_lb;
   uint64_t worst_draws = 0;
+  // the generator runs ahead in chunks; a round waits only for the chunk that covers its draws
+  struct RngChunk {
+    uint64_t hi;
+    hipEvent_t ev;
+  };
+  std::deque<RngChunk> rng_chunks;
+  std::vector<hipEvent_t> rng_event_pool;
+  // asynchronous snapshots of the streams' positions keep the host's bounds tight without syncing
+  static constexpr int NSNAP = 8;
+  unsigned long long* snap_host = nullptr;  // pinned [NSNAP][S]
+  hipEvent_t snap_ev[NSNAP] = {};
+  uint64_t snap_round[NSNAP] = {};
+  bool snap_pending[NSNAP] = {};
+  uint64_t rounds_submitted = 0;
   // capacities
   size_t fcap[CSL_MAX_LAYERS + 1];  // frontier capacity entering layer l
   size_t fcap_max = 0, ccap_max = 0;
@@ -1403,68 +1419,129 @@ int refresh_positions(csl_engine* e) {
   std::vector<unsigned long long> tmp(e->S);
   HIPCHECK(hipMemcpy(tmp.data(), e->rngpos, sizeof(unsigned long long) * e->S, hipMemcpyDeviceToHost));
   for (int s = 0; s < e->S; s++) e->pos_ub[s] = e->pos_lb[s] = tmp[s];
+  for (int k = 0; k < csl_engine::NSNAP; k++) e->snap_pending[k] = false;
   return 0;
 }
 
-// make sure the ring holds [min lower bound, max upper bound + one round)
-int ensure_rng(csl_engine* e) {
-  uint64_t need_hi = 0, lo = UINT64_MAX;
-  for (int s = 0; s < e->S; s++) {
-    if (e->pos_ub[s] + e->worst_draws > need_hi) need_hi = e->pos_ub[s] + e->worst_draws;
-    if (e->pos_lb[s] < lo) lo = e->pos_lb[s];
+// newest completed position snapshot -> tight bounds without a sync
+void poll_snapshots(csl_engine* e) {
+  int best = -1;
+  for (int k = 0; k < csl_engine::NSNAP; k++) {
+    if (!e->snap_pending[k]) continue;
+    if (hipEventQuery(e->snap_ev[k]) != hipSuccess) continue;
+    if (best < 0 || e->snap_round[k] > e->snap_round[best]) best = k;
   }
-  if (need_hi <= e->gen_hi) return 0;
-  // generate ahead: half a ring beyond the need, as far as the ring allows
-  uint64_t target = need_hi + e->ring_words / 2;
-  if (target > lo + e->ring_words) {
-    // upper bounds drift above the real positions; resync before giving up
-    if (e->dirty) {
-      for (int k = 0; k < e->nsets; k++) HIPCHECK(hipStreamSynchronize(e->streams[k]));
-      e->dirty = false;
-      int r = collect_timing(e);
-      if (r) return r;
+  if (best < 0) return;
+  const uint64_t after = e->rounds_submitted - (e->snap_round[best] + 1);  // rounds submitted since
+  const unsigned long long* sn = e->snap_host + (size_t)best * e->S;
+  for (int s = 0; s < e->S; s++) {
+    // a snapshot may mix two consecutive rounds' values: both are valid lower bounds
+    if (sn[s] > e->pos_lb[s]) e->pos_lb[s] = sn[s];
+    const uint64_t ub = sn[s] + after * e->worst_draws;
+    if (ub < e->pos_ub[s] && ub >= e->pos_lb[s]) e->pos_ub[s] = ub;
+  }
+  for (int k = 0; k < csl_engine::NSNAP; k++)
+    if (e->snap_pending[k] && e->snap_round[k] <= e->snap_round[best]) e->snap_pending[k] = false;
+}
+
+hipEvent_t rng_get_event(csl_engine* e) {
+  if (!e->rng_event_pool.empty()) {
+    hipEvent_t ev = e->rng_event_pool.back();
+    e->rng_event_pool.pop_back();
+    return ev;
+  }
+  hipEvent_t ev;
+  hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  return ev;
+}
+
+void rng_bounds(csl_engine* e, uint64_t* need_hi, uint64_t* lo) {
+  *need_hi = 0;
+  *lo = UINT64_MAX;
+  for (int s = 0; s < e->S; s++) {
+    if (e->pos_ub[s] + e->worst_draws > *need_hi) *need_hi = e->pos_ub[s] + e->worst_draws;
+    if (e->pos_lb[s] < *lo) *lo = e->pos_lb[s];
+  }
+}
+
+// Keep the ring filled up to LOOKAHEAD beyond what the next round may draw, in chunks on the rng
+// stream; hand back the event of the chunk that covers the next round (`*wait`, may be null when
+// that chunk is known complete) and the position up to which the round may read (`*safe_hi`).
+// The generator only ever overwrites words below every stream's lower bound.
+int ensure_rng(csl_engine* e, hipEvent_t* wait, uint64_t* safe_hi) {
+  poll_snapshots(e);
+  uint64_t need_hi, lo;
+  rng_bounds(e, &need_hi, &lo);
+  uint64_t lookahead = 4 * e->worst_draws;
+  if (lookahead < (1ull << 20)) lookahead = 1ull << 20;
+  if (lookahead > e->ring_words / 4) lookahead = e->ring_words / 4;
+  uint64_t chunk = 2 * e->worst_draws;
+  if (chunk < (1ull << 18)) chunk = 1ull << 18;
+  if (chunk > e->ring_words / 8) chunk = e->ring_words / 8;
+  chunk = (chunk / 624 + 1) * 624;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    while (e->gen_hi < need_hi + lookahead) {
+      uint64_t target = e->gen_hi + chunk;
+      if (target > lo + e->ring_words) target = lo + e->ring_words;
+      const uint32_t nblocks = target > e->gen_hi ? (uint32_t)((target - e->gen_hi) / 624) : 0;  // round down
+      if (nblocks == 0) break;  // the ring is full relative to the slowest stream
+      {
+        Timed t(e, KN_MT, e->rng_stream);
+        hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(TN), 0, e->rng_stream, e->mt_state, e->ring,
+                           (unsigned long long)(e->ring_words - 1), (unsigned long long)e->gen_hi, nblocks);
+      }
+      HIPCHECK(hipGetLastError());
+      e->gen_hi += (uint64_t)nblocks * 624ull;
+      csl_engine::RngChunk c;
+      c.hi = e->gen_hi;
+      c.ev = rng_get_event(e);
+      HIPCHECK(hipEventRecord(c.ev, e->rng_stream));
+      e->rng_chunks.push_back(c);
     }
-    int r = refresh_positions(e);
-    if (r) return r;
-    need_hi = 0;
-    lo = UINT64_MAX;
-    for (int s = 0; s < e->S; s++) {
-      if (e->pos_ub[s] + e->worst_draws > need_hi) need_hi = e->pos_ub[s] + e->worst_draws;
-      if (e->pos_lb[s] < lo) lo = e->pos_lb[s];
-    }
-    if (need_hi <= e->gen_hi) return 0;
-    target = need_hi + e->ring_words / 2;
-    if (target > lo + e->ring_words) target = lo + e->ring_words;
-    if (target < need_hi)
+    if (e->gen_hi >= need_hi) break;
+    if (attempt == 1)
       return fail(CSL_E_INVALID, "mt19937 ring too small: streams span %llu words, ring %llu (raise rng_ring_log2)",
                   (unsigned long long)(need_hi - lo), (unsigned long long)e->ring_words);
+    // the bounds drifted apart (or the ring is tight): settle everything and take exact positions
+    for (int k = 0; k < e->nsets; k++) HIPCHECK(hipStreamSynchronize(e->streams[k]));
+    e->dirty = false;
+    int r = collect_timing(e);
+    if (r) return r;
+    r = refresh_positions(e);
+    if (r) return r;
+    rng_bounds(e, &need_hi, &lo);
   }
-  const uint64_t words = target - e->gen_hi;
-  const uint32_t nblocks = (uint32_t)(words / 624);  // round down: never overwrite below `lo`
-  if (nblocks == 0) return fail(CSL_E_INVALID, "mt19937 ring too small for one round");
-  {
-    Timed t(e, KN_MT, e->rng_stream);
-    hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(TN), 0, e->rng_stream, e->mt_state, e->ring,
-                       (unsigned long long)(e->ring_words - 1), (unsigned long long)e->gen_hi, nblocks);
+  // retire chunks nobody can need any more, find the one this round waits for
+  while (e->rng_chunks.size() > 1 && e->rng_chunks.front().hi <= lo &&
+         hipEventQuery(e->rng_chunks.front().ev) == hipSuccess) {
+    e->rng_event_pool.push_back(e->rng_chunks.front().ev);
+    e->rng_chunks.pop_front();
   }
-  HIPCHECK(hipGetLastError());
-  e->gen_hi += (uint64_t)nblocks * 624ull;
-  if (e->gen_hi < need_hi) return fail(CSL_E_INVALID, "mt19937 ring too small for one round");
-  HIPCHECK(hipEventRecord(e->rng_event, e->rng_stream));
+  *wait = nullptr;
+  *safe_hi = e->gen_hi;
+  for (const auto& c : e->rng_chunks) {
+    if (c.hi >= need_hi) {
+      *wait = c.ev;
+      *safe_hi = c.hi;
+      break;
+    }
+  }
   return 0;
 }
 
 int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int32_t slot) {
   const int S = e->S, L = e->L;
-  int r = ensure_rng(e);
+  hipEvent_t rng_wait = nullptr;
+  uint64_t rng_safe_hi = 0;
+  int r = ensure_rng(e, &rng_wait, &rng_safe_hi);
   if (r) return r;
   // per-kernel timing wants undisturbed kernels: timed rounds all run on stream 0
-  const int set = (e->nsets > 1 && !e->timing) ? (slot & 1) : 0;
+  const int set = (e->nsets > 1 && !e->timing) ? (slot % e->nsets) : 0;
   hipStream_t st = e->streams[set];
   const size_t sF = (size_t)set * S * e->fcap_max, sC = (size_t)set * S * e->ccap_max;
   uint32_t* fsize = e->fsize + (size_t)set * S * (CSL_MAX_LAYERS + 1);
-  // the mt19937 window this round may read has been requested on the rng stream
-  HIPCHECK(hipStreamWaitEvent(st, e->rng_event, 0));
+  // wait for the generator chunk that covers this round's draws (requested rounds ago, normally done)
+  if (rng_wait) HIPCHECK(hipStreamWaitEvent(st, rng_wait, 0));
   // the generator may only overwrite ring words below every stream's position
   const unsigned long long gen_lo = e->gen_hi > e->ring_words ? e->gen_hi - e->ring_words : 0;
   BatchDesc* dd = e->desc_dev + (size_t)slot * S;
@@ -1489,7 +1566,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.ring = e->ring;
     a.ring_mask = e->ring_words - 1;
     a.gen_lo = gen_lo;
-    a.gen_hi = e->gen_hi;
+    a.gen_hi = rng_safe_hi;
     a.rngpos = e->rngpos;
     a.rngbase = e->rngbase + (size_t)set * S;
     a.acc = e->acc;
@@ -1554,9 +1631,18 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
       Timed t(e, KN_SCAN_A, st);
       hipLaunchKernelGGL(k_scan<0>, dim3(S), blk, 0, st, a);
     }
-    if (l == L - 1 && e->nsets > 1) {
-      HIPCHECK(hipEventRecord(e->chain_event, st));
-      e->chain_valid = true;
+    if (l == L - 1) {
+      if (e->nsets > 1) {
+        HIPCHECK(hipEventRecord(e->chain_event, st));
+        e->chain_valid = true;
+      }
+      const int k = (int)(e->rounds_submitted % csl_engine::NSNAP);
+      if (e->snap_pending[k]) HIPCHECK(hipEventSynchronize(e->snap_ev[k]));
+      HIPCHECK(hipMemcpyAsync(e->snap_host + (size_t)k * S, e->rngpos, sizeof(unsigned long long) * S,
+                              hipMemcpyDeviceToHost, st));
+      HIPCHECK(hipEventRecord(e->snap_ev[k], st));
+      e->snap_round[k] = e->rounds_submitted;
+      e->snap_pending[k] = true;
     }
     {
       Timed t(e, KN_SAMPLE, st);
@@ -1597,6 +1683,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
   }
   HIPCHECK(hipGetLastError());
   for (int s = 0; s < n_batches && s < S; s++) e->pos_ub[s] += e->worst_draws;
+  e->rounds_submitted++;
   HIPCHECK(hipEventRecord(e->slot_event[slot], st));
   e->slot_pending[slot] = 1;
   e->dirty = true;
@@ -1615,7 +1702,7 @@ const char* csl_kernel_name(int32_t k) { return (k >= 0 && k < CSL_NUM_KERNELS) 
 void csl_destroy(csl_engine* e) {
   if (!e) return;
   hipSetDevice(e->cfg.device);
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < CSL_MAX_SETS; k++)
     if (e->streams[k]) hipStreamSynchronize(e->streams[k]);
   if (e->rng_stream) hipStreamSynchronize(e->rng_stream);
   for (auto& te : e->timed) {
@@ -1639,9 +1726,14 @@ void csl_destroy(csl_engine* e) {
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
   if (e->rng_event) hipEventDestroy(e->rng_event);
   if (e->chain_event) hipEventDestroy(e->chain_event);
+  for (auto& c : e->rng_chunks) hipEventDestroy(c.ev);
+  for (auto ev : e->rng_event_pool) hipEventDestroy(ev);
+  for (int k = 0; k < csl_engine::NSNAP; k++)
+    if (e->snap_ev[k]) hipEventDestroy(e->snap_ev[k]);
+  if (e->snap_host) hipHostFree(e->snap_host);
   for (auto ev : e->slot_event) hipEventDestroy(ev);
   for (auto ev : e->desc_event) hipEventDestroy(ev);
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < CSL_MAX_SETS; k++)
     if (e->streams[k]) hipStreamDestroy(e->streams[k]);
   if (e->rng_stream) hipStreamDestroy(e->rng_stream);
   delete e;
@@ -1654,7 +1746,7 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   e->N = (uint32_t)cfg->num_nodes;
   e->E = (size_t)cfg->num_edges;
   HIPCHECK(hipSetDevice(cfg->device));
-  e->nsets = (cfg->n_slots >= 2 && !(cfg->flags & CSL_FLAG_SERIAL_ROUNDS)) ? 2 : 1;
+  e->nsets = (cfg->flags & CSL_FLAG_SERIAL_ROUNDS) ? 1 : (cfg->n_slots < CSL_MAX_SETS ? cfg->n_slots : CSL_MAX_SETS);
   for (int k = 0; k < e->nsets; k++) HIPCHECK(hipStreamCreateWithFlags(&e->streams[k], hipStreamNonBlocking));
   e->stream = e->streams[0];
   HIPCHECK(hipStreamCreateWithFlags(&e->rng_stream, hipStreamNonBlocking));
@@ -1813,6 +1905,8 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   e->pos_ub.assign(S, 0);
   e->pos_lb.assign(S, 0);
   e->gen_hi = 0;
+  HIPCHECK(hipHostMalloc((void**)&e->snap_host, sizeof(unsigned long long) * csl_engine::NSNAP * S, hipHostMallocDefault));
+  for (int k = 0; k < csl_engine::NSNAP; k++) HIPCHECK(hipEventCreateWithFlags(&e->snap_ev[k], hipEventDisableTiming));
   HIPCHECK(hipStreamSynchronize(e->stream));
   return 0;
 }
@@ -2105,7 +2199,7 @@ int64_t csl_copy_frontier(csl_engine* e, int32_t slot, int32_t stream, int32_t l
 int csl_hip_stream(csl_engine* e, int32_t slot, void** out) {
   if (!e || !out) return fail(CSL_E_INVALID, "null argument");
   if (slot < 0 || slot >= e->slots) return fail(CSL_E_INVALID, "slot out of range");
-  *out = (void*)e->streams[e->nsets > 1 ? (slot & 1) : 0];
+  *out = (void*)e->streams[e->nsets > 1 ? (slot % e->nsets) : 0];
   return 0;
 }
 
