@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--streams", type=int, default=128, help="S: minibatches per round")
     ap.add_argument("--batch", type=int, default=1024)
@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--slots", type=int, default=2, help="result slots = rounds in flight (engine streams/scratch sets)")
+    ap.add_argument("--slots", type=int, default=3, help="result slots = rounds in flight (engine streams/scratch sets)")
     ap.add_argument("--serial-rounds", action="store_true",
                     help="no overlap of consecutive rounds (profiling: undisturbed per-kernel durations)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")

@@ -50,10 +50,10 @@ def main():
     write, _ = pmc(os.path.join(src, "write"))
     with open(os.path.join(dst, "summary.md"), "w") as f:
         f.write("# rocprofv3 summary: %s\n\n" % os.path.basename(src))
-        f.write("Command: `profiles/run_profiles.sh` (bench.py --steps 10 --warmup 3 --no-cpu-baseline "
+        f.write("Command: `profiles/run_profiles.sh` (bench.py --steps 20 --warmup 5 --no-cpu-baseline "
                 "--no-kernel-timing --serial-rounds --e2e-steps 0; three separate runs: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE).\n\n")
         f.write("FETCH_SIZE / WRITE_SIZE are rocprofv3's raw values in KiB, summed over the launches of the run "
-                "(13 rounds x 3 layers = 39 launches per slicer kernel). MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of "
+                "(25 rounds x 3 layers = 75 launches per slicer kernel). MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of "
                 "the bytes of a wide coalesced stream (x2 correction); narrow random gathers are uncalibrated, so the "
                 "raw value is a lower bound and 2x raw an upper bound. WRITE_SIZE is exact for wide stores.\n\n")
         f.write("| kernel | calls | total ms | avg us | max us | % | FETCH_SIZE MiB/launch (raw) | WRITE_SIZE MiB/launch |\n")
