@@ -22,30 +22,32 @@ def orc():
     return oracle
 
 
-def test_rng_ring_wraps_many_rounds(abi, orc):
-    """A 2^16-word mt19937 window and ~120 rounds: every stream's position passes the window size
-    several times; the generator must stay ahead without overwriting words still to be read."""
+@pytest.mark.parametrize("n_slots,rounds", [(2, 120), (3, 400), (1, 60)])
+def test_rng_ring_wraps_many_rounds(abi, orc, n_slots, rounds):
+    """A 2^16-word mt19937 window and many rounds: every stream's position passes the window size
+    several times; the chunked generator must stay ahead without overwriting words still to be read,
+    with 1, 2 or 3 rounds in flight and the host submitting far ahead of the GPU."""
     from cslicer import l0
     n, B, S = 4000, 64, 3
     indptr, indices = l0.synth_graph(n, 40.0, seed=17)     # most rows draw (deg >= fanout)
     perm = np.random.default_rng(8).permutation(n)
-    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 10), max_batch=B, n_streams=S, n_slots=2,
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 10), max_batch=B, n_streams=S, n_slots=n_slots,
                    rng_ring_log2=16)
     e.set_nodes(perm)
     oracles = [orc.Oracle(indptr, indices, n_parts=4, fanouts=(10, 10)) for _ in range(S)]
     rounds_per_epoch = (n // B) // S
     total_draws = 0
-    for r in range(120):
+    for r in range(rounds):
         first = (r % rounds_per_epoch) * S
-        e.submit_round(first, B, S, slot=r & 1)
+        e.submit_round(first, B, S, slot=r % n_slots)
         want = [oracles[s].sample(perm[(first + s) * B:(first + s + 1) * B]) for s in range(S)]
-        if r % 17 == 0 or r == 119:      # most rounds are NOT fetched: host bounds drift, then resync
+        if r % 17 == 0 or r == rounds - 1:   # most rounds are NOT fetched: the host runs ahead
             for s in range(S):
-                got = e.sample_dict(s, slot=r & 1)
+                got = e.sample_dict(s, slot=r % n_slots)
                 assert_same_sample(got, want[s], what="round %d stream %d" % (r, s), check_traversal=False)
                 assert got["draws_total"] == want[s]["draws_total"]
                 total_draws = max(total_draws, got["draws_total"])
-    assert total_draws > 4 * (1 << 16), "the test must actually wrap the ring (%d draws)" % total_draws
+    assert total_draws > 2 * (1 << 16), "the test must actually wrap the ring (%d draws)" % total_draws
     e.close()
 
 
