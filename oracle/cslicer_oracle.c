@@ -14,6 +14,7 @@
  * Each function cites the reference file:line it restates (paths relative to
  * the reference's cslicer/ directory).
  */
+#define _POSIX_C_SOURCE 200809L /* clock_gettime */
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
