@@ -1166,25 +1166,33 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t l) {
   const uint32_t y = (u & 0x80000000u) | (l & 0x7fffffffu);
   return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
-__global__ __launch_bounds__(TN) void k_mt19937_fill(uint32_t* state, uint32_t* ring, unsigned long long ring_mask,
-                                                    unsigned long long pos0, uint32_t nblocks) {
+#ifndef CSL_MT_THREADS
+#define CSL_MT_THREADS 256
+#endif
+constexpr int MTT = CSL_MT_THREADS;  // 256 lanes per 227-word phase beat one wave (5.2 ms vs 1.9 ms per chunk)
+
+// (tried: one wave instead of 256 lanes -> 5.2 ms per 2 M-word chunk instead of 1.9 ms; an LDS-only
+// barrier instead of __syncthreads() -> no change: the three dependent LDS round trips per 624 words
+// set the pace, ~1.1 G words/s, about five times what the slicer consumes)
+__global__ __launch_bounds__(MTT) void k_mt19937_fill(uint32_t* state, uint32_t* ring, unsigned long long ring_mask,
+                                                     unsigned long long pos0, uint32_t nblocks) {
   __shared__ uint32_t buf[2][624];
   const uint32_t t = threadIdx.x;
-  for (uint32_t i = t; i < 624; i += TN) buf[0][i] = state[i];
+  for (uint32_t i = t; i < 624; i += MTT) buf[0][i] = state[i];
   __syncthreads();
   uint32_t cur = 0;
   for (uint32_t blk = 0; blk < nblocks; blk++) {
     const uint32_t* A = buf[cur];
     uint32_t* B = buf[cur ^ 1];
-    if (t < 227) B[t] = A[t + 397] ^ mt_twist(A[t], A[t + 1]);
+    for (uint32_t i = t; i < 227; i += MTT) B[i] = A[i + 397] ^ mt_twist(A[i], A[i + 1]);
     __syncthreads();
-    if (t < 227) B[227 + t] = B[t] ^ mt_twist(A[227 + t], A[228 + t]);
+    for (uint32_t i = t; i < 227; i += MTT) B[227 + i] = B[i] ^ mt_twist(A[227 + i], A[228 + i]);
     __syncthreads();
-    if (t < 169) B[454 + t] = B[227 + t] ^ mt_twist(A[454 + t], A[455 + t]);
-    if (t == 255) B[623] = B[396] ^ mt_twist(A[623], B[0]);
+    for (uint32_t i = t; i < 169; i += MTT) B[454 + i] = B[227 + i] ^ mt_twist(A[454 + i], A[455 + i]);
+    if (t == MTT - 1) B[623] = B[396] ^ mt_twist(A[623], B[0]);
     __syncthreads();
     const unsigned long long base = pos0 + (unsigned long long)blk * 624ull;
-    for (uint32_t i = t; i < 624; i += TN) {
+    for (uint32_t i = t; i < 624; i += MTT) {
       uint32_t y = B[i];
       y ^= y >> 11;
       y ^= (y << 7) & 0x9d2c5680u;
@@ -1195,7 +1203,7 @@ __global__ __launch_bounds__(TN) void k_mt19937_fill(uint32_t* state, uint32_t* 
     cur ^= 1;
   }
   __syncthreads();
-  for (uint32_t i = t; i < 624; i += TN) state[i] = buf[cur][i];
+  for (uint32_t i = t; i < 624; i += MTT) state[i] = buf[cur][i];
 }
 
 // packs the reference's int64 CSR into rowinfo / u32 indices on the device
@@ -1487,7 +1495,7 @@ int ensure_rng(csl_engine* e, hipEvent_t* wait, uint64_t* safe_hi) {
       if (nblocks == 0) break;  // the ring is full relative to the slowest stream
       {
         Timed t(e, KN_MT, e->rng_stream);
-        hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(TN), 0, e->rng_stream, e->mt_state, e->ring,
+        hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(MTT), 0, e->rng_stream, e->mt_state, e->ring,
                            (unsigned long long)(e->ring_words - 1), (unsigned long long)e->gen_hi, nblocks);
       }
       HIPCHECK(hipGetLastError());
@@ -2236,7 +2244,7 @@ int csl_rng_peek(csl_engine* e, uint64_t pos, uint32_t* dst, int64_t n) {
   while (e->gen_hi < pos + (uint64_t)n) {
     uint64_t words = pos + (uint64_t)n - e->gen_hi;
     uint32_t nblocks = (uint32_t)((words + 623) / 624);
-    hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(TN), 0, e->rng_stream, e->mt_state, e->ring,
+    hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(MTT), 0, e->rng_stream, e->mt_state, e->ring,
                        (unsigned long long)(e->ring_words - 1), (unsigned long long)e->gen_hi, nblocks);
     e->gen_hi += (uint64_t)nblocks * 624ull;
     HIPCHECK(hipStreamSynchronize(e->rng_stream));
