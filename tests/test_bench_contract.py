@@ -1,0 +1,50 @@
+"""bench.py's JSON line (the committed one from the last GPU run, profiles/<LATEST>/) carries every
+field the driver's contract asks for, with consistent values."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _latest():
+    latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
+    path = os.path.join(ROOT, "profiles", latest, "bench_default.json.log")
+    line = [l for l in open(path) if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_json_contract():
+    d = _latest()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "sampled_edges_per_sec" and d["unit"] == "edges/s" and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert "15/10/5" in d["config"]["workload"] and "2449029" in d["config"]["workload"]
+    # value and ms_per_step describe the same timed region
+    edges_per_step = d["config"]["sampled_edges_per_minibatch"] * d["config"]["minibatches_per_step"]
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / edges_per_step - 1.0) < 0.02
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert d["value"] > 50 * c["value"]      # sanity: the GPU path is not the CPU path in disguise
+
+
+def test_rocprof_stats_agree_with_bench_kernel_time():
+    """DESIGN/contract: the rocprofv3 --stats average of the dominant kernel (same command, same stream
+    count, serial rounds) agrees with the HIP-event average bench.py reports."""
+    import csv
+    d = _latest()
+    latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", latest, "kernel_stats.csv"))))
+    dom = d["roofline"]["kernel"]
+    row = [r for r in rows if ("::" + dom + "(") in r["Name"]][0]
+    prof_us = float(row["AverageNs"]) / 1e3
+    assert abs(prof_us / d["roofline"]["avg_launch_us"] - 1.0) < 0.10, (prof_us, d["roofline"]["avg_launch_us"])
