@@ -181,3 +181,36 @@ def test_running_totals_are_exact(abi, orc):
             want_edges += oracles[s].sample(perm[(r * 3 + s) * 100:(r * 3 + s + 1) * 100])["sampled_edges"]
     assert e.totals() == (want_edges, 12)
     e.close()
+
+
+def test_extreme_parameters(abi, orc):
+    """Limits of the configuration space: fanout 255 (candidate stride 256 = the tile width), four
+    layers, 7 parts, a single seed, hundreds of streams."""
+    from cslicer import l0
+    indptr, indices = l0.synth_graph(3000, 300.0, seed=23)
+    perm = np.random.default_rng(4).permutation(3000)
+    # fanout 255, 2 layers
+    e = abi.Engine(indptr, indices, n_parts=7, fanouts=(255, 2), max_batch=5, n_streams=2)
+    e.submit_seeds([perm[:5], perm[5:6]])
+    for s, seeds in enumerate([perm[:5], perm[5:6]]):
+        assert_same_sample(e.sample_dict(s), orc.Oracle(indptr, indices, n_parts=7, fanouts=(255, 2)).sample(seeds),
+                           what="fanout 255 stream %d" % s)
+    e.close()
+    # four layers
+    indptr, indices = l0.synth_graph(20000, 8.0, seed=24)
+    perm = np.random.default_rng(5).permutation(20000)
+    e = abi.Engine(indptr, indices, n_parts=3, fanouts=(4, 3, 3, 2), max_batch=50, n_streams=1)
+    e.submit_seeds([perm[:50]])
+    assert_same_sample(e.sample_dict(0), orc.Oracle(indptr, indices, n_parts=3, fanouts=(4, 3, 3, 2)).sample(perm[:50]),
+                       what="four layers")
+    e.close()
+    # many streams, tiny minibatches
+    S = 300
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(5, 5), max_batch=4, n_streams=S, n_slots=2)
+    e.set_nodes(perm)
+    e.submit_round(0, 4, S)
+    for s in (0, 1, 137, 299):
+        want = orc.Oracle(indptr, indices, n_parts=4, fanouts=(5, 5)).sample(perm[s * 4:(s + 1) * 4])
+        assert_same_sample(e.sample_dict(s), want, what="stream %d of 300" % s)
+    assert e.totals()[1] == S
+    e.close()
