@@ -204,6 +204,12 @@ int csl_fetch_sample32(csl_engine* e, int32_t slot, int32_t stream, csl_sample_m
  * `long`; the host exports above (csl_copy_list, csl_fetch_sample) widen to int64. */
 int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int32_t kind,
                         const int32_t** out);
+/* the whole result arena of `layer` at once, for consumers that build their views once:
+ * *base = int32 array of [n_slots][n_streams][*stride] elements; list kind k of (slot, stream)
+ * starts at ((slot * n_streams + stream) * stride + list_base[k]) */
+int csl_arena_info(csl_engine* e, int32_t layer, const int32_t** base, int64_t* stride,
+                   int64_t list_base[CSL_NUM_LISTS]);
+
 /* device pointer of the frontier entering `layer` (0..n_layers; n_layers = the
  * nodes whose features the model reads); uint32 ids; length in meta */
 int csl_frontier_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, const uint32_t** out);

@@ -33,7 +33,7 @@ SYMBOLS = [
     "csl_submit_round", "csl_submit_seeds", "csl_sync", "csl_get_meta", "csl_copy_list",
     "csl_list_device_ptr", "csl_frontier_device_ptr", "csl_copy_frontier", "csl_hip_stream",
     "csl_timing_enable", "csl_timing_read", "csl_kernel_name", "csl_rng_peek", "csl_device_bytes",
-    "csl_fetch_sample", "csl_fetch_sample32", "csl_totals",
+    "csl_fetch_sample", "csl_fetch_sample32", "csl_totals", "csl_arena_info",
 ]
 
 
@@ -127,6 +127,7 @@ def load():
     L.csl_kernel_name.restype = C.c_char_p
     L.csl_rng_peek.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32), C.c_int64]
     L.csl_totals.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.csl_arena_info.argtypes = [vp, C.c_int32, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int64 * NUM_LISTS)]
     L.csl_device_bytes.argtypes = [vp]
     L.csl_device_bytes.restype = C.c_int64
     if L.csl_abi_version() != ABI_VERSION:
@@ -350,6 +351,12 @@ class Engine:
         out = np.empty(n, dtype=np.uint32)
         _check(load().csl_rng_peek(self._h, pos, out.ctypes.data_as(C.POINTER(C.c_uint32)), n))
         return out
+
+    def arena_info(self, layer):
+        """(device pointer, elements per (slot, stream), [list base offsets]) of a layer's result arena."""
+        p, stride, lb = C.c_void_p(), C.c_int64(0), (C.c_int64 * NUM_LISTS)()
+        _check(load().csl_arena_info(self._h, layer, C.byref(p), C.byref(stride), C.byref(lb)))
+        return p.value, int(stride.value), [int(x) for x in lb]
 
     def totals(self):
         """(sampled edges, minibatches) sliced since creation, all streams; waits for submitted rounds."""

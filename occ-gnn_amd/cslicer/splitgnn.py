@@ -52,24 +52,43 @@ class Slice(object):
                  "self_ids_in", "owned_degree", "from_ids", "to_ids", "n_in", "n_out", "n_owned")
 
 
-def slices_of(eng, stream=0, slot=0, parts=None, device=None):
+def _arena_tensors(eng, device):
+    """One int32 tensor per layer over the engine's whole result arena, built once per engine:
+    per-sample views are then plain tensor slices (torch.as_tensor on a raw pointer costs tens of
+    microseconds; a training step needs ~40 views)."""
+    cache = getattr(eng, "_arena_cache", None)
+    if cache is None or cache[0] != device:
+        layers = []
+        for l in range(eng.n_layers):
+            ptr, stride, lbase = eng.arena_info(l)
+            t = torch.as_tensor(_DevArray(ptr, eng.n_slots * eng.n_streams * stride), device=device)
+            layers.append((t, stride, lbase))
+        cache = (device, layers)
+        eng._arena_cache = cache
+    return cache[1]
+
+
+def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
     """All layers x parts of one sample as `Slice`s (layer 0 = hop from the seeds).
     parts: iterable of part ids to materialise (default all)."""
     if eng.mode != _abi.MODE_GRAPH:
         raise ValueError("splitgnn needs an engine created with mode=MODE_GRAPH")
     device = device or torch.device("cuda", torch.cuda.current_device())
-    m = eng.meta(stream, slot)          # waits for the round that filled the slot
+    m = meta if meta is not None else eng.meta(stream, slot)   # waits for the round that filled the slot
     P = eng.n_parts
     parts = range(P) if parts is None else parts
+    arenas = _arena_tensors(eng, device)
     out = []
     for l in range(eng.n_layers):
         lm = m.layer[l]
-        base = {k: eng.list_device_ptr(l, k, stream, slot) for k in range(_abi.NUM_LISTS)}
+        t, stride, lbase = arenas[l]
+        origin = (slot * eng.n_streams + stream) * stride
 
         def seg(kind, g, lo=None, hi=None):
             a = int(lm.off[kind][g]) if lo is None else lo
             b = int(lm.off[kind][g + 1]) if hi is None else hi
-            return _view_i32(base[kind] + 4 * a, b - a, device)
+            o = origin + lbase[kind]
+            return t[o + a:o + b]
 
         row = {}
         for g in parts:

@@ -50,7 +50,8 @@ class Trainer(object):
 
     def _step(self, stream, slot):
         t0 = time.perf_counter()
-        slices = splitgnn.slices_of(self.eng, stream, slot, parts=[self.rank], device=self.dev)
+        meta = self.eng.meta(stream, slot)
+        slices = splitgnn.slices_of(self.eng, stream, slot, parts=[self.rank], device=self.dev, meta=meta)
         self.t_slice += time.perf_counter() - t0
         deep = slices[self.L - 1][self.rank]
         x = self.feat[(deep.in_nodes // self.P).long()]  # gather of owned input features
@@ -63,7 +64,7 @@ class Trainer(object):
         seeds = top.out_nodes[top.owned_out_nodes.long()]  # the seeds this rank owns, frontier order
         y = self.labels[(seeds // self.P).long()]
         # mean over the WHOLE minibatch: sum of local losses / global seed count
-        n_seeds = int(self.eng.meta(stream, slot).n_seeds)
+        n_seeds = int(meta.n_seeds)
         loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / max(n_seeds, 1)
         self.t_forward += time.perf_counter() - t1
         self.opt.zero_grad(set_to_none=True)

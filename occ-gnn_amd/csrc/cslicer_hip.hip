@@ -2176,6 +2176,16 @@ int csl_list_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t lay
   return 0;
 }
 
+int csl_arena_info(csl_engine* e, int32_t layer, const int32_t** base, int64_t* stride,
+                   int64_t list_base[CSL_NUM_LISTS]) {
+  if (!e || !base || !stride || !list_base) return fail(CSL_E_INVALID, "null argument");
+  if (layer < 0 || layer >= e->L) return fail(CSL_E_INVALID, "layer out of range");
+  *base = (const int32_t*)e->arena[layer];
+  *stride = (int64_t)e->arena_stride[layer];
+  for (int k = 0; k < CSL_NUM_LISTS; k++) list_base[k] = (int64_t)e->list_base[layer][k];
+  return 0;
+}
+
 int csl_frontier_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, const uint32_t** out) {
   if (!e || !out) return fail(CSL_E_INVALID, "null argument");
   if (slot < 0 || slot >= e->slots || stream < 0 || stream >= e->S || layer < 0 || layer > e->L)

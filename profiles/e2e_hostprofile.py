@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Host-side profile (cProfile) of the end-to-end training step: where a 1.7 ms step spends its
+Python/launch time.  usage: python3 profiles/e2e_hostprofile.py [steps]"""
+import cProfile
+import os
+import pstats
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "occ-gnn_amd"))
+from cslicer import l0  # noqa: E402
+from cslicer.train import Trainer, synthetic_node_data  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+cache = os.path.join(os.environ.get("CSLICER_BENCH_CACHE", "/tmp/cslicer_bench_cache"), "g_n2449029_d50.5_s0")
+if os.path.exists(os.path.join(cache, "ok")):
+    indptr, indices = np.load(os.path.join(cache, "indptr.npy")), np.load(os.path.join(cache, "indices.npy"))
+else:
+    indptr, indices = l0.synth_graph(2_449_029, 50.5, seed=0)
+n = indptr.shape[0] - 1
+feats, labels = synthetic_node_data(n, 100, 47)
+t = Trainer(indptr, indices, feats, labels, 47, fanouts=(15, 10, 5), batch=1024, streams=8, hidden=256)
+t.set_nodes(np.random.default_rng(1).permutation(n))
+t.run(16)
+pr = cProfile.Profile()
+pr.enable()
+t.run(steps, first_batch=16)
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(22)
