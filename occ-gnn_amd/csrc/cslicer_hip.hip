@@ -700,7 +700,7 @@ __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
 // of its node (a) in the next frontier (out_dr mask, slicer.cpp:45-49) and
 // (b) among the in_nodes of its slice (order_and_remove_duplicates,
 // bipartite.cpp:4).  flag byte: bit0 new-frontier, bit1 first-in-node,
-// bits2-4 owner part.
+// bits2-4 owner part, bit5 the node is also a frontier node of this layer.
 __device__ __forceinline__ uint32_t ht_find(const uint32_t* h_key, uint32_t val) {
   uint32_t h = slot_of(val);
   for (uint32_t probes = 0; probes < (uint32_t)HCAP; probes++) {
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
       const uint32_t self = h_self[h];
       const uint32_t fe = epos == c;
       const uint32_t newf = a.graph ? fe : (fe && (self == UNSET || (unsigned long long)self * W > c));
-      if (fe) cflag[c] = (uint8_t)(newf | (fe << 1) | (g << 2));
+      if (fe) cflag[c] = (uint8_t)(newf | (fe << 1) | (g << 2) | (self != UNSET ? 32u : 0u));
       if (a.graph) a.srcpos[(size_t)s * a.ccap + c] = epos;
     }
   };
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(TN) void k_count(LArgs a) {
 #pragma unroll
     for (int b = 0; b < 4; b++) {
       const uint32_t fl = (w >> (8 * b)) & 0xFFu;
-      const uint32_t fe = (fl >> 1) & 1u, g = fl >> 2;
+      const uint32_t fe = (fl >> 1) & 1u, g = (fl >> 2) & 7u;
 #pragma unroll
       for (int gg = 0; gg < CSL_MAX_PARTS; gg++) cnt[1 + gg] += (fe && g == (uint32_t)gg) ? 1u : 0u;
     }
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   }
   for (uint32_t it = 0; it < iters; it++) {
     const uint32_t k = it * TN + n;
-    uint32_t newf = 0, fe = 0, g = 0, val = 0;
+    uint32_t newf = 0, fe = 0, g = 0, val = 0, crk = 0;
     {
       uint32_t fl = 0;
       if (it < (uint32_t)EP) {
@@ -910,7 +910,8 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       }
       newf = fl & 1u;
       fe = (fl >> 1) & 1u;
-      g = fl >> 2;
+      g = (fl >> 2) & 7u;
+      crk = a.graph | ((fl >> 5) & 1u);
     }
     const uint32_t b = it & 1;
     const unsigned long long m0 = __ballot(newf);
@@ -939,7 +940,9 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       p += TB(K_IN(P, g));  // local index inside slice g's in_nodes
 #ifndef CSL_ABLATE_EMIT_IN
       ar[a.list_base[CSL_IN_NODES] + m.off[CSL_IN_NODES][g] + p] = (int)val;
-      a.crank[cbase + k] = p;  // DuplicateRemover::replace's lookup value (mask[v]-1)
+      // DuplicateRemover::replace's lookup value (mask[v]-1): read back by k_selfin for candidates whose
+      // node is in the frontier (flag bit 5) and by k_graph for every edge
+      if (crk) a.crank[cbase + k] = p;
 #endif
     }
     __syncthreads();
