@@ -221,36 +221,47 @@ __global__ __launch_bounds__(TN) void k_seeds(const long long* __restrict__ node
 // offset and degree of every frontier node; counts rng consumers and sampled
 // edges per tile.
 __global__ __launch_bounds__(TN) void k_degree(LArgs a) {
-  uint32_t tile, s;
-  if (!xcd_block(a, tile, s)) return;
+  // one wave per tile, four consecutive nodes per lane: no LDS, no barrier
+  uint32_t bx, s;
+  if (!xcd_block(a, bx, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  const uint32_t tile = bx * NW + (threadIdx.x >> 6);
   if (tile * TN >= F) return;
-  const uint32_t i = tile * TN + threadIdx.x;
+  const uint32_t i0 = tile * TN + lane_id() * 4;
+  unsigned long long ri[4] = {0, 0, 0, 0};
+  if (a.layer == 0) {
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = i0 + j < F ? a.fr_in[s * a.fr_in_stride + i0 + j] : UNSET;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (v[j] != UNSET) ri[j] = a.rowinfo[v[j]];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (v[j] != UNSET) a.ninfo[s * a.fcap + i0 + j] = ri[j];
+  } else {
+    // gathered by the previous layer's k_emit
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (i0 + j < F) ri[j] = a.ninfo[s * a.fcap + i0 + j];
+  }
   uint32_t need = 0, ne = 0;
-  if (i < F) {
-    unsigned long long ri;
-    if (a.layer == 0) {
-      ri = a.rowinfo[a.fr_in[s * a.fr_in_stride + i]];
-      a.ninfo[s * a.fcap + i] = ri;
-    } else {
-      ri = a.ninfo[s * a.fcap + i];  // gathered by the previous layer's k_emit
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (i0 + j < F) {
+      const uint32_t deg = (uint32_t)(ri[j] & DEG_MASK);
+      need += deg >= a.fanout;
+      ne += deg < a.fanout ? deg : a.fanout;
     }
-    const uint32_t deg = (uint32_t)(ri & DEG_MASK);
-    need = deg >= a.fanout;
-    ne = deg < a.fanout ? deg : a.fanout;
   }
-  __shared__ uint32_t s_cnt[2];
-  if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t wn = __popcll(__ballot(need));
-  uint32_t we = ne;
-  for (int o = 32; o > 0; o >>= 1) we += __shfl_down(we, o);
+  for (int o = 32; o > 0; o >>= 1) {
+    need += __shfl_down(need, o);
+    ne += __shfl_down(ne, o);
+  }
   if (lane_id() == 0) {
-    atomicAdd(&s_cnt[0], wn);
-    atomicAdd(&s_cnt[1], we);
+    a.tcnt[((size_t)s * a.nk + K_NEED) * a.tmax + tile] = need;
+    a.tcnt[((size_t)s * a.nk + K_EDGES) * a.tmax + tile] = ne;
   }
-  __syncthreads();
-  if (threadIdx.x < 2) a.tcnt[((size_t)s * a.nk + threadIdx.x) * a.tmax + tile] = s_cnt[threadIdx.x];
 }
 
 // ---- k_scan: exclusive scan of tile counters kinds [k_lo, k_hi) per stream,
@@ -265,27 +276,50 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t x, uint32_t& total) 
   return incl - x;
 }
 
+constexpr int SCAN_T = 1024;  // k_scan<1>: 16 waves share the 3+6P (or more) kinds of a stream
+constexpr int SCAN_CH = 12;    // tiles a lane keeps in registers (64 x 12 tiles = 196 k frontier nodes)
+
 template <int PHASE>
-__global__ __launch_bounds__(TN) void k_scan(LArgs a) {
+__global__ __launch_bounds__(PHASE == 0 ? TN : SCAN_T) void k_scan(LArgs a) {
   const int s = blockIdx.x;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
   const uint32_t ntiles = (F + TN - 1) / TN;
   const int k_lo = PHASE == 0 ? 0 : 2;
   const int k_hi = PHASE == 0 ? 2 : (int)a.nk;
   __shared__ uint32_t s_tot[MAXK];
-  const int w = threadIdx.x >> 6;
-  for (int k = k_lo + w; k < k_hi; k += NW) {
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const uint32_t chunk = (ntiles + 63) / 64;  // consecutive tiles per lane
+  for (int k = k_lo + w; k < k_hi; k += nw) {
     uint32_t* p = a.tcnt + ((size_t)s * a.nk + k) * a.tmax;
-    uint32_t run = 0;
-    for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
-      const uint32_t t = t0 + lane_id();
-      const uint32_t x = t < ntiles ? p[t] : 0;
+    if (chunk <= (uint32_t)SCAN_CH) {
+      // all of the lane's counters are requested at once; one wave scan of the lane sums
+      const uint32_t t0 = lane_id() * chunk;
+      uint32_t x[SCAN_CH], sum = 0;
+#pragma unroll
+      for (int j = 0; j < SCAN_CH; j++) {
+        x[j] = ((uint32_t)j < chunk && t0 + j < ntiles) ? p[t0 + j] : 0u;
+        sum += x[j];
+      }
       uint32_t tot;
-      const uint32_t ex = wave_excl_scan(x, tot);
-      if (t < ntiles) p[t] = run + ex;
-      run += tot;
+      uint32_t run = wave_excl_scan(sum, tot);
+#pragma unroll
+      for (int j = 0; j < SCAN_CH; j++) {
+        if ((uint32_t)j < chunk && t0 + j < ntiles) p[t0 + j] = run;
+        run += x[j];
+      }
+      if (lane_id() == 0) s_tot[k] = tot;
+    } else {
+      uint32_t run = 0;
+      for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
+        const uint32_t t = t0 + lane_id();
+        const uint32_t x = t < ntiles ? p[t] : 0;
+        uint32_t tot;
+        const uint32_t ex = wave_excl_scan(x, tot);
+        if (t < ntiles) p[t] = run + ex;
+        run += tot;
+      }
+      if (lane_id() == 0) s_tot[k] = run;
     }
-    if (lane_id() == 0) s_tot[k] = run;
   }
   if (PHASE == 0) {
     // bucket geometry of this layer: enough buckets that a bucket's distinct
@@ -295,7 +329,7 @@ __global__ __launch_bounds__(TN) void k_scan(LArgs a) {
     if (nb < 1) nb = 1;
     if (nb > a.nbmax) nb = a.nbmax;
     if (threadIdx.x == 0) a.nbk[s] = F ? nb : 0;
-    for (uint32_t b = threadIdx.x; b <= a.nbmax; b += TN) a.bcnt[(size_t)s * (a.nbmax + 1) + b] = 0;
+    for (uint32_t b = threadIdx.x; b <= a.nbmax; b += blockDim.x) a.bcnt[(size_t)s * (a.nbmax + 1) + b] = 0;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -864,103 +898,111 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   if (!xcd_block(a, tile, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
   if (tile * TN >= F) return;
-  const uint32_t n = threadIdx.x, w = n >> 6;
+  const uint32_t n = threadIdx.x;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(n >> 6);  // wave-uniform, kept in an SGPR
+  const uint32_t lane = lane_id();
   const uint32_t W = a.W, P = a.P;
   const csl_layer_meta& m = a.meta[s].layer[a.layer];
   int* ar = a.arena + (size_t)s * a.arena_stride;
   const uint32_t* tc = a.tcnt + (size_t)s * a.nk * a.tmax;
 #define TB(kind) tc[(size_t)(kind)*a.tmax + tile]
-  __shared__ uint32_t s_wc[2][NW][1 + CSL_MAX_PARTS];
-  __shared__ uint32_t s_run[1 + CSL_MAX_PARTS];
+  __shared__ uint32_t s_wc[2][NW][1 + CSL_MAX_PARTS];  // per-wave counts of a step (double-buffered)
+  __shared__ uint32_t s_run[2][1 + CSL_MAX_PARTS];     // list position of the step's first candidate
   __shared__ uint32_t s_wn[NW][5 * CSL_MAX_PARTS];
-  if (n < 1 + CSL_MAX_PARTS) s_run[n] = 0;
-  // ---- candidate-level lists: next frontier, in_nodes
+  __shared__ uint32_t s_tb[5 * CSL_MAX_PARTS];         // tile bases of the node-level lists
+  __shared__ uint32_t s_mo[6][CSL_MAX_PARTS];          // part offsets: in_nodes + the five node-level lists
+  // Everything that does not depend on this block's own stores is requested NOW: the tile bases and part
+  // offsets (a load of them between two stores would wait for a full memory round trip every step, the
+  // compiler cannot prove they do not alias the lists) and the node-level phase's inputs.
+  if (n < 1 + P) s_run[0][n] = n == 0 ? TB(K_NEWF) : TB(K_IN(P, n - 1));
+  if (n >= 64 && n < 64 + 5 * P) s_tb[n - 64] = TB(K_OUT(P, 0) + (n - 64));  // kinds OUT, OWNED, SELF, TO, FROM
+  if (n >= 128 && n < 128 + 6 * CSL_MAX_PARTS) {
+    const uint32_t k6 = (n - 128) / CSL_MAX_PARTS, g = (n - 128) % CSL_MAX_PARTS;
+    const int list = k6 == 0 ? CSL_IN_NODES : k6 == 1 ? CSL_OUT_NODES : k6 == 2 ? CSL_OWNED_OUT_NODES
+                   : k6 == 3 ? CSL_SELF_IDS_OUT : k6 == 4 ? CSL_TO_IDS : CSL_FROM_IDS;
+    s_mo[k6][g] = g < P ? m.off[list][g] : 0u;
+  }
+  const uint32_t i = tile * TN + n;
+  const bool act = i < F;
+  uint32_t v = 0, hb = 0;
+  if (act) {
+    v = a.fr_in[s * a.fr_in_stride + i];
+    hb = a.hasedge[s * a.fcap + i];
+  }
+  // ---- candidate-level lists: next frontier, in_nodes.  Step `it` covers candidates it*TN..it*TN+TN-1
+  // of the tile; traversal order = (step, wave, lane): ballot ranks inside the wave, per-wave counts
+  // through LDS, ONE barrier per step (counts and running positions are double-buffered).
   const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
   const uint32_t ncand = nodes_here * W;
   const uint32_t iters = (ncand + TN - 1) / TN;
   const size_t cbase = (size_t)s * a.ccap + (size_t)tile * TN * W;
   const uint32_t nf_cap = m.next_frontier;  // already clamped to capacity
-  // the thread's flags and ids for the first EP steps are requested up front
-  // (independent loads); the loop itself then only ranks and stores
-  uint32_t pf[EP], pv[EP];
+  const unsigned long long lt = lt_mask();
+  uint32_t* fr_out = a.fr_out + s * a.fr_out_stride;
+  unsigned long long* ninfo = a.ninfo + s * a.fcap;
+  int* in_list = ar + a.list_base[CSL_IN_NODES];
+  for (uint32_t c0 = 0; c0 < iters; c0 += EP) {
+    // flags and ids of the chunk's EP steps are requested up front (independent loads)
+    uint32_t pf[EP], pv[EP];
 #pragma unroll
-  for (int j = 0; j < EP; j++) {
-    const uint32_t k = j * TN + n;
-    pf[j] = ((uint32_t)j < iters && k < ncand) ? a.cflag[cbase + k] : 0u;
-  }
+    for (int j = 0; j < EP; j++) {
+      const uint32_t k = (c0 + j) * TN + n;
+      pf[j] = k < ncand ? a.cflag[cbase + k] : 0u;
+    }
 #pragma unroll
-  for (int j = 0; j < EP; j++) {
-    const uint32_t k = j * TN + n;
-    pv[j] = (pf[j] & 3u) ? a.cand[cbase + k] : 0u;
-  }
-  for (uint32_t it = 0; it < iters; it++) {
-    const uint32_t k = it * TN + n;
-    uint32_t newf = 0, fe = 0, g = 0, val = 0, crk = 0;
-    {
-      uint32_t fl = 0;
-      if (it < (uint32_t)EP) {
+    for (int j = 0; j < EP; j++) {
+      const uint32_t k = (c0 + j) * TN + n;
+      pv[j] = (pf[j] & 3u) ? a.cand[cbase + k] : 0u;
+    }
 #pragma unroll
-        for (int j = 0; j < EP; j++) {
-          fl = (uint32_t)j == it ? pf[j] : fl;
-          val = (uint32_t)j == it ? pv[j] : val;
+    for (int j = 0; j < EP; j++) {
+      if (c0 + j >= iters) break;  // block-uniform
+      const uint32_t b = j & 1;    // EP is even: the buffer parity carries over from chunk to chunk
+      const uint32_t fl = pf[j], val = pv[j];
+      const uint32_t newf = fl & 1u, fe = (fl >> 1) & 1u, g = (fl >> 2) & 7u;
+      const unsigned long long m0 = __ballot(newf);
+      const uint32_t r0 = __popcll(m0 & lt);
+      uint32_t rE = 0;
+      if (lane == 0) s_wc[b][w][0] = __popcll(m0);
+#pragma unroll
+      for (uint32_t gg = 0; gg < CSL_MAX_PARTS; gg++) {
+        if (gg < P) {
+          const unsigned long long mg = __ballot(fe && g == gg);
+          if (g == gg) rE = __popcll(mg & lt);
+          if (lane == 0) s_wc[b][w][1 + gg] = __popcll(mg);
         }
-      } else if (k < ncand) {
-        fl = a.cflag[cbase + k];
-        if (fl & 3u) val = a.cand[cbase + k];
       }
-      newf = fl & 1u;
-      fe = (fl >> 1) & 1u;
-      g = (fl >> 2) & 7u;
-      crk = a.graph | ((fl >> 5) & 1u);
-    }
-    const uint32_t b = it & 1;
-    const unsigned long long m0 = __ballot(newf);
-    const uint32_t r0 = __popcll(m0 & lt_mask());
-    if (lane_id() == 0) s_wc[b][w][0] = __popcll(m0);
-    uint32_t rE = 0;
-    for (uint32_t gg = 0; gg < P; gg++) {
-      const unsigned long long mg = __ballot(fe && g == gg);
-      if (fe && g == gg) rE = __popcll(mg & lt_mask());
-      if (lane_id() == 0) s_wc[b][w][1 + gg] = __popcll(mg);
-    }
-    __syncthreads();
-    if (newf) {
-      uint32_t p = s_run[0] + r0;
-      for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][0];
-      p += TB(K_NEWF);
-      if (p < nf_cap) {
-        a.fr_out[s * a.fr_out_stride + p] = val;
-        // the next layer's row lookup rides on this pass (slicer.cpp:8-9)
-        if (!a.last) a.ninfo[s * a.fcap + p] = a.rowinfo[val];
+      __syncthreads();
+      if (n < 1 + P) {  // position of the next step's first candidate
+        uint32_t t = s_run[b][n];
+#pragma unroll
+        for (uint32_t ww = 0; ww < NW; ww++) t += s_wc[b][ww][n];
+        s_run[b ^ 1][n] = t;
       }
-    }
-    if (fe) {
-      uint32_t p = s_run[1 + g] + rE;
-      for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][1 + g];
-      p += TB(K_IN(P, g));  // local index inside slice g's in_nodes
+      if (newf) {
+        uint32_t p = s_run[b][0] + r0;
+        for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][0];
+        if (p < nf_cap) {
+          fr_out[p] = val;
+          // the next layer's row lookup rides on this pass (slicer.cpp:8-9)
+          if (!a.last) ninfo[p] = a.rowinfo[val];
+        }
+      }
 #ifndef CSL_ABLATE_EMIT_IN
-      ar[a.list_base[CSL_IN_NODES] + m.off[CSL_IN_NODES][g] + p] = (int)val;
-      // DuplicateRemover::replace's lookup value (mask[v]-1): read back by k_selfin for candidates whose
-      // node is in the frontier (flag bit 5) and by k_graph for every edge
-      if (crk) a.crank[cbase + k] = p;
+      if (fe) {
+        uint32_t p = s_run[b][1 + g] + rE;  // local index inside slice g's in_nodes
+        for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][1 + g];
+        in_list[s_mo[0][g] + p] = (int)val;
+        // DuplicateRemover::replace's lookup value (mask[v]-1): read back by k_selfin for candidates whose
+        // node is in the frontier (flag bit 5) and by k_graph for every edge
+        if (a.graph || (fl & 32u)) a.crank[cbase + (c0 + j) * TN + n] = p;
+      }
 #endif
     }
-    __syncthreads();
-    if (n < 1 + P) {
-      uint32_t t = 0;
-      for (uint32_t ww = 0; ww < NW; ww++) t += s_wc[b][ww][n];
-      s_run[n] += t;
-    }
   }
+  static_assert(EP % 2 == 0, "buffer parity");
   // ---- node-level lists: out_nodes, owned_out_nodes, self_ids_out, to_ids, from_ids
-  const uint32_t i = tile * TN + n;
-  const bool act = i < F;
-  uint32_t v = 0, hb = 0, to = 0;
-  if (act) {
-    v = a.fr_in[s * a.fr_in_stride + i];
-    hb = a.hasedge[s * a.fcap + i];
-    to = owner(a, v);
-  }
+  const uint32_t to = act ? owner(a, v) : 0u;
   uint32_t r_out[CSL_MAX_PARTS];
   uint32_t r_owned = 0, r_self = 0, r_to = 0, r_from[CSL_MAX_PARTS];
 #pragma unroll
@@ -975,7 +1017,6 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       const unsigned long long b_self = __ballot(own);
       const unsigned long long b_to = __ballot(own && (hb & ~(1u << g)) != 0);
       const unsigned long long b_from = __ballot(has && !own);
-      const unsigned long long lt = lt_mask();
       r_out[g] = __popcll(b_out & lt);
       r_from[g] = __popcll(b_from & lt);
       if (own) {
@@ -983,7 +1024,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
         r_self = __popcll(b_self & lt);
         r_to = __popcll(b_to & lt);
       }
-      if (lane_id() == 0) {
+      if (lane == 0) {
         s_wn[w][0 * CSL_MAX_PARTS + g] = __popcll(b_out);
         s_wn[w][1 * CSL_MAX_PARTS + g] = __popcll(b_owned);
         s_wn[w][2 * CSL_MAX_PARTS + g] = __popcll(b_self);
@@ -999,39 +1040,34 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
 #pragma unroll
     for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
       if (g < P && ((hb >> g) & 1u)) {
-        uint32_t p = r_out[g];
+        uint32_t p = r_out[g] + s_tb[0 * P + g];  // local index inside slice g's out_nodes
         for (uint32_t ww = 0; ww < w; ww++) p += s_wn[ww][0 * CSL_MAX_PARTS + g];
-        p += TB(K_OUT(P, g));  // local index inside slice g's out_nodes
-        ar[a.list_base[CSL_OUT_NODES] + m.off[CSL_OUT_NODES][g] + p] = (int)v;
+        ar[a.list_base[CSL_OUT_NODES] + s_mo[1][g] + p] = (int)v;
         if (g == to) {
           outrank_to = p;
         } else if (!a.graph) {
-          uint32_t q = r_from[g];
+          uint32_t q = r_from[g] + s_tb[4 * P + g];
           for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][4 * CSL_MAX_PARTS + g];
-          q += TB(K_FROM(P, g));
-          ar[a.list_base[CSL_FROM_IDS] + m.off[CSL_FROM_IDS][g] + q] = (int)p;
+          ar[a.list_base[CSL_FROM_IDS] + s_mo[5][g] + q] = (int)p;
         }
       }
     }
     {
-      uint32_t q = r_self;
+      uint32_t q = r_self + s_tb[2 * P + to];
       for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][2 * CSL_MAX_PARTS + to];
-      q += TB(K_SELF(P, to));
-      const uint32_t pos = m.off[CSL_SELF_IDS_OUT][to] + q;
+      const uint32_t pos = s_mo[3][to] + q;
       ar[a.list_base[CSL_SELF_IDS_OUT] + pos] = outrank_to;
       a.selfpos[s * a.fcap + i] = pos;  // k_selfin fills self_ids_in at the same place
     }
     if (outrank_to >= 0) {
-      uint32_t q = r_owned;
+      uint32_t q = r_owned + s_tb[1 * P + to];
       for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][1 * CSL_MAX_PARTS + to];
-      q += TB(K_OWNED(P, to));
-      ar[a.list_base[CSL_OWNED_OUT_NODES] + m.off[CSL_OWNED_OUT_NODES][to] + q] = outrank_to;
+      ar[a.list_base[CSL_OWNED_OUT_NODES] + s_mo[2][to] + q] = outrank_to;
     }
     if (!a.graph && (hb & ~(1u << to)) != 0) {
-      uint32_t q = r_to;
+      uint32_t q = r_to + s_tb[3 * P + to];
       for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][3 * CSL_MAX_PARTS + to];
-      q += TB(K_TO(P, to));
-      ar[a.list_base[CSL_TO_IDS] + m.off[CSL_TO_IDS][to] + q] = outrank_to;
+      ar[a.list_base[CSL_TO_IDS] + s_mo[4][to] + q] = outrank_to;
     }
   }
 #else
@@ -1633,7 +1669,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     const size_t lds_hist = (size_t)e->nbmax * sizeof(uint32_t);
     {
       Timed t(e, KN_DEGREE, st);
-      hipLaunchKernelGGL(k_degree, grid_in, blk, 0, st, a);
+      hipLaunchKernelGGL(k_degree, dim3(xg * ((tiles_in + NW - 1) / NW)), blk, 0, st, a);
     }
     // the stream's mt19937 position is handed from round to round: this round's first update
     // waits for the previous round's last one (its k_seeds / first k_degree did not have to)
@@ -1677,7 +1713,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     }
     {
       Timed t(e, KN_SCAN_B, st);
-      hipLaunchKernelGGL(k_scan<1>, dim3(S), blk, 0, st, a);
+      hipLaunchKernelGGL(k_scan<1>, dim3(S), dim3(SCAN_T), 0, st, a);
     }
     {
       Timed t(e, KN_EMIT, st);
