@@ -906,9 +906,15 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   int* ar = a.arena + (size_t)s * a.arena_stride;
   const uint32_t* tc = a.tcnt + (size_t)s * a.nk * a.tmax;
 #define TB(kind) tc[(size_t)(kind)*a.tmax + tile]
-  __shared__ uint32_t s_wc[2][NW][1 + CSL_MAX_PARTS];  // per-wave counts of a step (double-buffered)
-  __shared__ uint32_t s_run[2][1 + CSL_MAX_PARTS];     // list position of the step's first candidate
-  __shared__ uint32_t s_wn[NW][5 * CSL_MAX_PARTS];
+  // per-wave counts (<= 64) are BYTES of one word per kind: a wave's prefix over the waves before it is
+  // one masked v_sad_u8 instead of a loop of LDS reads
+  static_assert(NW == 4, "four wave counts per word");
+  __shared__ uint32_t s_wc[2][1 + CSL_MAX_PARTS];   // a step's counts (double-buffered)
+  __shared__ uint32_t s_run[2][1 + CSL_MAX_PARTS];  // list position of the step's first candidate
+  __shared__ uint32_t s_wn[5 * CSL_MAX_PARTS];      // node-level counts
+  const uint32_t below = (1u << (8u * w)) - 1u;     // byte lanes of the waves before this one
+#define WBYTE(word) (reinterpret_cast<uint8_t*>(&(word))[w])
+#define BYTESUM(x) __builtin_amdgcn_sad_u8((x), 0u, 0u)
   __shared__ uint32_t s_tb[5 * CSL_MAX_PARTS];         // tile bases of the node-level lists
   __shared__ uint32_t s_mo[6][CSL_MAX_PARTS];          // part offsets: in_nodes + the five node-level lists
   // Everything that does not depend on this block's own stores is requested NOW: the tile bases and part
@@ -963,25 +969,19 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       const unsigned long long m0 = __ballot(newf);
       const uint32_t r0 = __popcll(m0 & lt);
       uint32_t rE = 0;
-      if (lane == 0) s_wc[b][w][0] = __popcll(m0);
+      if (lane == 0) WBYTE(s_wc[b][0]) = (uint8_t)__popcll(m0);
 #pragma unroll
       for (uint32_t gg = 0; gg < CSL_MAX_PARTS; gg++) {
         if (gg < P) {
           const unsigned long long mg = __ballot(fe && g == gg);
           if (g == gg) rE = __popcll(mg & lt);
-          if (lane == 0) s_wc[b][w][1 + gg] = __popcll(mg);
+          if (lane == 0) WBYTE(s_wc[b][1 + gg]) = (uint8_t)__popcll(mg);
         }
       }
       __syncthreads();
-      if (n < 1 + P) {  // position of the next step's first candidate
-        uint32_t t = s_run[b][n];
-#pragma unroll
-        for (uint32_t ww = 0; ww < NW; ww++) t += s_wc[b][ww][n];
-        s_run[b ^ 1][n] = t;
-      }
+      if (n < 1 + P) s_run[b ^ 1][n] = s_run[b][n] + BYTESUM(s_wc[b][n]);  // the next step's first candidate
       if (newf) {
-        uint32_t p = s_run[b][0] + r0;
-        for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][0];
+        const uint32_t p = s_run[b][0] + r0 + BYTESUM(s_wc[b][0] & below);
         if (p < nf_cap) {
           fr_out[p] = val;
           // the next layer's row lookup rides on this pass (slicer.cpp:8-9)
@@ -990,8 +990,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
       }
 #ifndef CSL_ABLATE_EMIT_IN
       if (fe) {
-        uint32_t p = s_run[b][1 + g] + rE;  // local index inside slice g's in_nodes
-        for (uint32_t ww = 0; ww < w; ww++) p += s_wc[b][ww][1 + g];
+        const uint32_t p = s_run[b][1 + g] + rE + BYTESUM(s_wc[b][1 + g] & below);  // local index inside slice g's in_nodes
         in_list[s_mo[0][g] + p] = (int)val;
         // DuplicateRemover::replace's lookup value (mask[v]-1): read back by k_selfin for candidates whose
         // node is in the frontier (flag bit 5) and by k_graph for every edge
@@ -1025,11 +1024,11 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
         r_to = __popcll(b_to & lt);
       }
       if (lane == 0) {
-        s_wn[w][0 * CSL_MAX_PARTS + g] = __popcll(b_out);
-        s_wn[w][1 * CSL_MAX_PARTS + g] = __popcll(b_owned);
-        s_wn[w][2 * CSL_MAX_PARTS + g] = __popcll(b_self);
-        s_wn[w][3 * CSL_MAX_PARTS + g] = __popcll(b_to);
-        s_wn[w][4 * CSL_MAX_PARTS + g] = __popcll(b_from);
+        WBYTE(s_wn[0 * CSL_MAX_PARTS + g]) = (uint8_t)__popcll(b_out);
+        WBYTE(s_wn[1 * CSL_MAX_PARTS + g]) = (uint8_t)__popcll(b_owned);
+        WBYTE(s_wn[2 * CSL_MAX_PARTS + g]) = (uint8_t)__popcll(b_self);
+        WBYTE(s_wn[3 * CSL_MAX_PARTS + g]) = (uint8_t)__popcll(b_to);
+        WBYTE(s_wn[4 * CSL_MAX_PARTS + g]) = (uint8_t)__popcll(b_from);
       }
     }
   }
@@ -1040,33 +1039,28 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
 #pragma unroll
     for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
       if (g < P && ((hb >> g) & 1u)) {
-        uint32_t p = r_out[g] + s_tb[0 * P + g];  // local index inside slice g's out_nodes
-        for (uint32_t ww = 0; ww < w; ww++) p += s_wn[ww][0 * CSL_MAX_PARTS + g];
+        const uint32_t p = r_out[g] + s_tb[0 * P + g] + BYTESUM(s_wn[0 * CSL_MAX_PARTS + g] & below);  // local index inside slice g's out_nodes
         ar[a.list_base[CSL_OUT_NODES] + s_mo[1][g] + p] = (int)v;
         if (g == to) {
           outrank_to = p;
         } else if (!a.graph) {
-          uint32_t q = r_from[g] + s_tb[4 * P + g];
-          for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][4 * CSL_MAX_PARTS + g];
+          const uint32_t q = r_from[g] + s_tb[4 * P + g] + BYTESUM(s_wn[4 * CSL_MAX_PARTS + g] & below);
           ar[a.list_base[CSL_FROM_IDS] + s_mo[5][g] + q] = (int)p;
         }
       }
     }
     {
-      uint32_t q = r_self + s_tb[2 * P + to];
-      for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][2 * CSL_MAX_PARTS + to];
+      const uint32_t q = r_self + s_tb[2 * P + to] + BYTESUM(s_wn[2 * CSL_MAX_PARTS + to] & below);
       const uint32_t pos = s_mo[3][to] + q;
       ar[a.list_base[CSL_SELF_IDS_OUT] + pos] = outrank_to;
       a.selfpos[s * a.fcap + i] = pos;  // k_selfin fills self_ids_in at the same place
     }
     if (outrank_to >= 0) {
-      uint32_t q = r_owned + s_tb[1 * P + to];
-      for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][1 * CSL_MAX_PARTS + to];
+      const uint32_t q = r_owned + s_tb[1 * P + to] + BYTESUM(s_wn[1 * CSL_MAX_PARTS + to] & below);
       ar[a.list_base[CSL_OWNED_OUT_NODES] + s_mo[2][to] + q] = outrank_to;
     }
     if (!a.graph && (hb & ~(1u << to)) != 0) {
-      uint32_t q = r_to + s_tb[3 * P + to];
-      for (uint32_t ww = 0; ww < w; ww++) q += s_wn[ww][3 * CSL_MAX_PARTS + to];
+      const uint32_t q = r_to + s_tb[3 * P + to] + BYTESUM(s_wn[3 * CSL_MAX_PARTS + to] & below);
       ar[a.list_base[CSL_TO_IDS] + s_mo[4][to] + q] = outrank_to;
     }
   }
@@ -1074,6 +1068,8 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   if (act) a.selfpos[s * a.fcap + i] = 0;
 #endif
 #undef TB
+#undef WBYTE
+#undef BYTESUM
 }
 
 // ---- k_graph (CSL_MODE_GRAPH only): what BiPartite::add_edge was meant to build
