@@ -276,6 +276,23 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t x, uint32_t& total) 
   return incl - x;
 }
 
+// Inclusive wave64 prefix sum on the VALU's DPP path (no LDS traffic, unlike __shfl_up): Hillis-Steele
+// inside each row of 16 lanes (row_shr 1,2,4,8), then lane 15 of rows 0/2 into rows 1/3 (row_bcast15),
+// then lane 31 into the upper half (row_bcast31) -- the sequence LLVM's atomic optimizer emits on GFX9.
+// Packed counters (several small fields in one word) scan in one go as long as no field overflows.
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x) {
+  int v = (int)x;
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return (uint32_t)v;
+}
+// bit g of x (g < 4) -> byte g
+__device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
+
 constexpr int SCAN_T = 1024;  // k_scan<1>: 16 waves share the 3+6P (or more) kinds of a stream
 constexpr int SCAN_CH = 12;    // tiles a lane keeps in registers (64 x 12 tiles = 196 k frontier nodes)
 
@@ -856,26 +873,48 @@ __global__ __launch_bounds__(TN) void k_count(LArgs a) {
   const uint32_t nbytes = nodes_here * W;
   // tile bases are multiples of 256 bytes: word loads are aligned
   const uint32_t* fw = reinterpret_cast<const uint32_t*>(a.cflag + (size_t)s * a.ccap + (size_t)tile * TN * W);
-  uint32_t cnt[1 + CSL_MAX_PARTS];
-#pragma unroll
-  for (int k = 0; k < 1 + CSL_MAX_PARTS; k++) cnt[k] = 0;
+  // first-in-node counts of the parts are 16-bit fields of two 64-bit accumulators (a lane sees at most
+  // 4*W <= 1024 flags): one shift and one add per flag byte instead of a compare chain per part
+  uint32_t c_new = 0;
+  unsigned long long acc_lo = 0, acc_hi = 0;  // parts 0-3, 4-7
   for (uint32_t o = lane_id() * 4; o < nbytes; o += 256) {
     uint32_t w = fw[o >> 2];
     if (o + 4 > nbytes) w &= 0xFFFFFFFFu >> (8 * (o + 4 - nbytes));  // bytes past the tile's candidates
-    cnt[0] += __popc(w & 0x01010101u);
+    c_new += __popc(w & 0x01010101u);
 #pragma unroll
     for (int b = 0; b < 4; b++) {
       const uint32_t fl = (w >> (8 * b)) & 0xFFu;
-      const uint32_t fe = (fl >> 1) & 1u, g = (fl >> 2) & 7u;
-#pragma unroll
-      for (int gg = 0; gg < CSL_MAX_PARTS; gg++) cnt[1 + gg] += (fe && g == (uint32_t)gg) ? 1u : 0u;
+      const unsigned long long one = (unsigned long long)((fl >> 1) & 1u) << (16u * ((fl >> 2) & 3u));
+      if (P > 4 && (fl & 16u)) acc_hi += one; else acc_lo += one;
     }
   }
+  uint32_t cnt[1 + CSL_MAX_PARTS];
+  if (nbytes < 65536u) {
+    // a tile total fits its 16-bit field: reduce the packed words
+    for (int o = 32; o > 0; o >>= 1) {
+      c_new += __shfl_down(c_new, o);
+      acc_lo += __shfl_down(acc_lo, o);
+      if (P > 4) acc_hi += __shfl_down(acc_hi, o);
+    }
+    cnt[0] = c_new;
 #pragma unroll
-  for (int k = 0; k < 1 + CSL_MAX_PARTS; k++) {
-    uint32_t x = cnt[k];
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
-    cnt[k] = x;
+    for (int g = 0; g < 4; g++) {
+      cnt[1 + g] = (uint32_t)(acc_lo >> (16 * g)) & 0xFFFFu;
+      cnt[5 + g] = (uint32_t)(acc_hi >> (16 * g)) & 0xFFFFu;
+    }
+  } else {
+    cnt[0] = c_new;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      cnt[1 + g] = (uint32_t)(acc_lo >> (16 * g)) & 0xFFFFu;
+      cnt[5 + g] = (uint32_t)(acc_hi >> (16 * g)) & 0xFFFFu;
+    }
+#pragma unroll
+    for (int k = 0; k < 1 + CSL_MAX_PARTS; k++) {
+      uint32_t x = cnt[k];
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+      cnt[k] = x;
+    }
   }
   if (lane_id() == 0) {
 #pragma unroll
@@ -911,7 +950,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   static_assert(NW == 4, "four wave counts per word");
   __shared__ uint32_t s_wc[2][1 + CSL_MAX_PARTS];   // a step's counts (double-buffered)
   __shared__ uint32_t s_run[2][1 + CSL_MAX_PARTS];  // list position of the step's first candidate
-  __shared__ uint32_t s_wn[5 * CSL_MAX_PARTS];      // node-level counts
+  __shared__ uint32_t s_wn[5 * 2 * NW];             // node-level counts: [kind][word][wave]
   const uint32_t below = (1u << (8u * w)) - 1u;     // byte lanes of the waves before this one
 #define WBYTE(word) (reinterpret_cast<uint8_t*>(&(word))[w])
 #define BYTESUM(x) __builtin_amdgcn_sad_u8((x), 0u, 0u)
@@ -1000,73 +1039,92 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
     }
   }
   static_assert(EP % 2 == 0, "buffer parity");
-  // ---- node-level lists: out_nodes, owned_out_nodes, self_ids_out, to_ids, from_ids
+  // ---- node-level lists: out_nodes, owned_out_nodes, self_ids_out, to_ids, from_ids.  A node's
+  // membership in the P lists of a kind is one word of byte counters (parts 0-3; a second word for parts
+  // 4-7): ONE wave scan per kind and word ranks it in all parts at once; a wave's total goes to LDS as one
+  // word, and the counts of the (<= 3) waves before it still fit a byte (<= 192 + 63).
   const uint32_t to = act ? owner(a, v) : 0u;
-  uint32_t r_out[CSL_MAX_PARTS];
-  uint32_t r_owned = 0, r_self = 0, r_to = 0, r_from[CSL_MAX_PARTS];
+  const uint32_t ob = act ? 1u << to : 0u;
+  const uint32_t oth = hb & ~ob;                                   // parts other than the owner with an edge
+  const bool hi = P > 4;                                           // block-uniform
+  const uint32_t one_to = act ? 1u << (8u * (to & 3u)) : 0u;       // the owner's byte ...
+  const bool to_hi = to >= 4;                                      // ... of the second word?
+  uint32_t wd[5][2];  // kinds OUT, OWNED, SELF, TO, FROM (the order of s_tb / the tile counters)
+  wd[0][0] = spread4(hb);
+  wd[4][0] = spread4(oth);
+  wd[1][0] = (!to_hi && (hb & ob)) ? one_to : 0u;
+  wd[2][0] = !to_hi ? one_to : 0u;
+  wd[3][0] = (!to_hi && oth) ? one_to : 0u;
+  wd[0][1] = wd[1][1] = wd[2][1] = wd[3][1] = wd[4][1] = 0;
+  if (hi) {
+    wd[0][1] = spread4(hb >> 4);
+    wd[4][1] = spread4(oth >> 4);
+    wd[1][1] = (to_hi && (hb & ob)) ? one_to : 0u;
+    wd[2][1] = to_hi ? one_to : 0u;
+    wd[3][1] = (to_hi && oth) ? one_to : 0u;
+  }
 #pragma unroll
-  for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
-    r_out[g] = 0;
-    r_from[g] = 0;
-    if (g < P) {
-      const bool own = act && to == g;
-      const bool has = act && ((hb >> g) & 1u);
-      const unsigned long long b_out = __ballot(has);
-      const unsigned long long b_owned = __ballot(own && has);
-      const unsigned long long b_self = __ballot(own);
-      const unsigned long long b_to = __ballot(own && (hb & ~(1u << g)) != 0);
-      const unsigned long long b_from = __ballot(has && !own);
-      r_out[g] = __popcll(b_out & lt);
-      r_from[g] = __popcll(b_from & lt);
-      if (own) {
-        r_owned = __popcll(b_owned & lt);
-        r_self = __popcll(b_self & lt);
-        r_to = __popcll(b_to & lt);
-      }
-      if (lane == 0) {
-        WBYTE(s_wn[0 * CSL_MAX_PARTS + g]) = (uint8_t)__popcll(b_out);
-        WBYTE(s_wn[1 * CSL_MAX_PARTS + g]) = (uint8_t)__popcll(b_owned);
-        WBYTE(s_wn[2 * CSL_MAX_PARTS + g]) = (uint8_t)__popcll(b_self);
-        WBYTE(s_wn[3 * CSL_MAX_PARTS + g]) = (uint8_t)__popcll(b_to);
-        WBYTE(s_wn[4 * CSL_MAX_PARTS + g]) = (uint8_t)__popcll(b_from);
+  for (int k = 0; k < 5; k++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (h == 0 || hi) {
+        const uint32_t incl = wave_incl_scan_dpp(wd[k][h]);
+        if (lane == 63) s_wn[(k * 2 + h) * NW + w] = incl;  // the wave's counts
+        wd[k][h] = incl - wd[k][h];                         // ranks inside the wave
       }
     }
   }
   __syncthreads();
+  const uint32_t m0 = w > 0 ? 0xFFFFFFFFu : 0u, m1 = w > 1 ? 0xFFFFFFFFu : 0u, m2 = w > 2 ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (h == 0 || hi) {
+        const uint32_t* c = &s_wn[(k * 2 + h) * NW];
+        wd[k][h] += (c[0] & m0) + (c[1] & m1) + (c[2] & m2);  // + the waves before this one
+      }
+    }
+  }
+#define RANK(k, g) ((wd[k][(g) >> 2] >> (8u * ((g)&3u))) & 0xFFu)
 #ifndef CSL_ABLATE_EMIT_NODES
   if (act) {
     int outrank_to = -1;
 #pragma unroll
     for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
       if (g < P && ((hb >> g) & 1u)) {
-        const uint32_t p = r_out[g] + s_tb[0 * P + g] + BYTESUM(s_wn[0 * CSL_MAX_PARTS + g] & below);  // local index inside slice g's out_nodes
+        const uint32_t p = RANK(0, g) + s_tb[0 * P + g];  // local index inside slice g's out_nodes
         ar[a.list_base[CSL_OUT_NODES] + s_mo[1][g] + p] = (int)v;
         if (g == to) {
           outrank_to = p;
         } else if (!a.graph) {
-          const uint32_t q = r_from[g] + s_tb[4 * P + g] + BYTESUM(s_wn[4 * CSL_MAX_PARTS + g] & below);
+          const uint32_t q = RANK(4, g) + s_tb[4 * P + g];
           ar[a.list_base[CSL_FROM_IDS] + s_mo[5][g] + q] = (int)p;
         }
       }
     }
+    const uint32_t tsh = 8u * (to & 3u);
+#define RANK_TO(k) (((to_hi ? wd[k][1] : wd[k][0]) >> tsh) & 0xFFu)
     {
-      const uint32_t q = r_self + s_tb[2 * P + to] + BYTESUM(s_wn[2 * CSL_MAX_PARTS + to] & below);
+      const uint32_t q = RANK_TO(2) + s_tb[2 * P + to];
       const uint32_t pos = s_mo[3][to] + q;
       ar[a.list_base[CSL_SELF_IDS_OUT] + pos] = outrank_to;
       a.selfpos[s * a.fcap + i] = pos;  // k_selfin fills self_ids_in at the same place
     }
     if (outrank_to >= 0) {
-      const uint32_t q = r_owned + s_tb[1 * P + to] + BYTESUM(s_wn[1 * CSL_MAX_PARTS + to] & below);
+      const uint32_t q = RANK_TO(1) + s_tb[1 * P + to];
       ar[a.list_base[CSL_OWNED_OUT_NODES] + s_mo[2][to] + q] = outrank_to;
     }
-    if (!a.graph && (hb & ~(1u << to)) != 0) {
-      const uint32_t q = r_to + s_tb[3 * P + to] + BYTESUM(s_wn[3 * CSL_MAX_PARTS + to] & below);
+    if (!a.graph && oth != 0) {
+      const uint32_t q = RANK_TO(3) + s_tb[3 * P + to];
       ar[a.list_base[CSL_TO_IDS] + s_mo[4][to] + q] = outrank_to;
     }
+#undef RANK_TO
   }
 #else
   if (act) a.selfpos[s * a.fcap + i] = 0;
 #endif
+#undef RANK
 #undef TB
 #undef WBYTE
 #undef BYTESUM
