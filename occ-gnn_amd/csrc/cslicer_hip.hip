@@ -783,29 +783,28 @@ __device__ __forceinline__ uint32_t ht_insert(uint32_t* h_key, uint32_t val) {
   return UNSET;
 }
 
+#ifndef CSL_BPB
+#define CSL_BPB 2
+#endif
+constexpr int BPB = CSL_BPB;  // buckets a block resolves one after the other; the next one's entries are in flight meanwhile
+
 __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
-  uint32_t b, s;
-  if (!xcd_block(a, b, s)) return;
-  if (b >= a.nbk[s]) return;
-  __shared__ uint32_t h_key[HCAP];
-  __shared__ uint32_t h_epos[HCAP];
-  __shared__ uint32_t h_self[HCAP];
+  uint32_t bx, s;
+  if (!xcd_block(a, bx, s)) return;
+  const uint32_t nbk = a.nbk[s];
+  uint32_t b = bx * BPB;
+  if (b >= nbk) return;
+  __shared__ __attribute__((aligned(16))) uint32_t h_key[HCAP];
+  __shared__ __attribute__((aligned(16))) uint32_t h_epos[HCAP];
+  __shared__ __attribute__((aligned(16))) uint32_t h_self[HCAP];
   const uint32_t n = threadIdx.x;
   const uint32_t* off = a.bcnt + (size_t)s * (a.nbmax + 1);
-  const uint32_t q0 = off[b], q1 = off[b + 1];
-  const uint2* q = a.queue + (size_t)s * a.ccap + q0;
-  const uint32_t cnt = q1 - q0;
+  const uint2* qs = a.queue + (size_t)s * a.ccap;
   const uint32_t W = a.W;
+  uint32_t q0 = off[b], q1 = off[b + 1];
   uint2 e[RC];
-  uint32_t hs[RC];
 #pragma unroll
-  for (int r = 0; r < RC; r++) e[r] = n + r * BT < cnt ? q[n + r * BT] : make_uint2(UNSET, 0u);
-  for (uint32_t i = n; i < (uint32_t)HCAP; i += BT) {
-    h_key[i] = UNSET;
-    h_epos[i] = UNSET;
-    h_self[i] = UNSET;
-  }
-  __syncthreads();
+  for (int r = 0; r < RC; r++) e[r] = n + r * BT < q1 - q0 ? qs[q0 + n + r * BT] : make_uint2(UNSET, 0u);
   auto insert = [&](const uint2 ee) -> uint32_t {
     const uint32_t h = ht_insert(h_key, ee.x);
     if (h == UNSET) {
@@ -820,10 +819,6 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     }
     return h;
   };
-#pragma unroll
-  for (int r = 0; r < RC; r++) hs[r] = e[r].x != UNSET ? insert(e[r]) : UNSET;
-  for (uint32_t k = n + RC * BT; k < cnt; k += BT) insert(q[k]);
-  __syncthreads();
   uint8_t* cflag = a.cflag + (size_t)s * a.ccap;
   auto evaluate = [&](const uint2 ee, const uint32_t h) {
     const uint32_t epos = h_epos[h];
@@ -849,13 +844,48 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
       if (a.graph) a.srcpos[(size_t)s * a.ccap + c] = epos;
     }
   };
+  for (int j = 0; j < BPB; j++, b++) {
+    if (b >= nbk) break;  // block-uniform
+    const uint2* q = qs + q0;
+    const uint32_t cnt = q1 - q0;
+    // the next bucket's first entries are requested before this one is resolved
+    uint2 en[RC];
+    uint32_t q1n = q1;
+    const bool more = j + 1 < BPB && b + 1 < nbk;
+    if (more) {
+      q1n = off[b + 2];
 #pragma unroll
-  for (int r = 0; r < RC; r++)
-    if (hs[r] != UNSET) evaluate(e[r], hs[r]);
-  for (uint32_t k = n + RC * BT; k < cnt; k += BT) {
-    const uint2 ee = q[k];
-    const uint32_t h = ht_find(h_key, ee.x);
-    if (h != UNSET) evaluate(ee, h);  // UNSET: table overflow, already flagged
+      for (int r = 0; r < RC; r++) en[r] = n + r * BT < q1n - q1 ? qs[q1 + n + r * BT] : make_uint2(UNSET, 0u);
+    }
+    {
+      // 16-byte LDS stores: 6 per thread instead of 24
+      const uint4 u4 = make_uint4(UNSET, UNSET, UNSET, UNSET);
+      for (uint32_t i = n; i < (uint32_t)HCAP / 4; i += BT) {
+        reinterpret_cast<uint4*>(h_key)[i] = u4;
+        reinterpret_cast<uint4*>(h_epos)[i] = u4;
+        reinterpret_cast<uint4*>(h_self)[i] = u4;
+      }
+    }
+    __syncthreads();
+    uint32_t hs[RC];
+#pragma unroll
+    for (int r = 0; r < RC; r++) hs[r] = e[r].x != UNSET ? insert(e[r]) : UNSET;
+    for (uint32_t k = n + RC * BT; k < cnt; k += BT) insert(q[k]);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RC; r++)
+      if (hs[r] != UNSET) evaluate(e[r], hs[r]);
+    for (uint32_t k = n + RC * BT; k < cnt; k += BT) {
+      const uint2 ee = q[k];
+      const uint32_t h = ht_find(h_key, ee.x);
+      if (h != UNSET) evaluate(ee, h);  // UNSET: table overflow, already flagged
+    }
+    if (!more) break;
+    __syncthreads();  // the table is rebuilt for the next bucket
+#pragma unroll
+    for (int r = 0; r < RC; r++) e[r] = en[r];
+    q0 = q1;
+    q1 = q1n;
   }
 }
 
@@ -986,18 +1016,18 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
   uint32_t* fr_out = a.fr_out + s * a.fr_out_stride;
   unsigned long long* ninfo = a.ninfo + s * a.fcap;
   int* in_list = ar + a.list_base[CSL_IN_NODES];
+  const uint8_t* __restrict__ cflag = a.cflag;
+  const uint32_t* __restrict__ cand = a.cand;
   for (uint32_t c0 = 0; c0 < iters; c0 += EP) {
-    // flags and ids of the chunk's EP steps are requested up front (independent loads)
+    // flags AND ids of the chunk's EP steps are requested up front: an id is only used where a flag is
+    // set, but waiting for the flag first puts one more memory round trip on the block's critical path
+    // (182 vs 202 us per launch)
     uint32_t pf[EP], pv[EP];
 #pragma unroll
     for (int j = 0; j < EP; j++) {
       const uint32_t k = (c0 + j) * TN + n;
-      pf[j] = k < ncand ? a.cflag[cbase + k] : 0u;
-    }
-#pragma unroll
-    for (int j = 0; j < EP; j++) {
-      const uint32_t k = (c0 + j) * TN + n;
-      pv[j] = (pf[j] & 3u) ? a.cand[cbase + k] : 0u;
+      pf[j] = k < ncand ? cflag[cbase + k] : 0u;
+      pv[j] = k < ncand ? cand[cbase + k] : 0u;
     }
 #pragma unroll
     for (int j = 0; j < EP; j++) {
@@ -1241,15 +1271,27 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
 // in-node rank of each frontier node inside its own slice, -1 if it was never
 // sampled as a neighbour.
 __global__ __launch_bounds__(TN) void k_selfin(LArgs a) {
+  // four nodes per thread (stride TN, coalesced), all gathers in flight before the stores
   uint32_t bx, s;
   if (!xcd_block(a, bx, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
-  const uint32_t i = bx * TN + threadIdx.x;
-  if (i >= F) return;
-  const uint32_t fp = a.firstpos[s * a.fcap + i];
-  int* ar = a.arena + (size_t)s * a.arena_stride;
-  ar[a.list_base[CSL_SELF_IDS_IN] + a.selfpos[s * a.fcap + i]] =
-      fp == UNSET ? -1 : (int)a.crank[(size_t)s * a.ccap + fp];
+  const uint32_t i0 = bx * 4 * TN + threadIdx.x;
+  if (bx * 4 * TN >= F) return;
+  int* ar = a.arena + (size_t)s * a.arena_stride + a.list_base[CSL_SELF_IDS_IN];
+  const uint32_t* __restrict__ crank = a.crank + (size_t)s * a.ccap;
+  uint32_t fp[4], sp[4];
+  int r[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t i = i0 + j * TN;
+    fp[j] = i < F ? a.firstpos[s * a.fcap + i] : UNSET;
+    sp[j] = i < F ? a.selfpos[s * a.fcap + i] : UNSET;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) r[j] = fp[j] == UNSET ? -1 : (int)crank[fp[j]];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if (sp[j] != UNSET) ar[sp[j]] = r[j];
 }
 
 // ---- k_mt19937_fill: the std::mt19937 stream (slicer.h:33), generated on the
@@ -1719,7 +1761,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     const dim3 grid_scatter(xg * (unsigned)((ccap_l + SCT - 1) / SCT));
     unsigned nb_l = (unsigned)((ccap_l + QMEAN - 1) / QMEAN);
     if (nb_l > e->nbmax) nb_l = e->nbmax;
-    const dim3 grid_bucket(xg * nb_l);
+    const dim3 grid_bucket(xg * ((nb_l + BPB - 1) / BPB));
     const size_t lds_hist = (size_t)e->nbmax * sizeof(uint32_t);
     {
       Timed t(e, KN_DEGREE, st);
@@ -1779,7 +1821,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     }
     {
       Timed t(e, KN_SELFIN, st);
-      hipLaunchKernelGGL(k_selfin, grid_in, blk, 0, st, a);
+      hipLaunchKernelGGL(k_selfin, dim3(xg * ((tiles_in + 3) / 4)), blk, 0, st, a);
     }
   }
   HIPCHECK(hipGetLastError());
