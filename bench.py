@@ -123,7 +123,8 @@ def kernel_bytes_device_layout(name, m, P, layer=0, last=False):
         # flags, ids of flagged candidates, next frontier, in_nodes + ranks, node lists,
         # and (not on the last layer) the next layer's rowinfo gather + ninfo store
         # (lists are int32 on the device)
-        return (C * 1 + (U + m["in_total"]) * 4 + U * 4 + m["in_total"] * (4 + 4)
+        # (the in-node rank `crank` is stored only for candidates whose node is in the frontier: <= F)
+        return (C * 1 + (U + m["in_total"]) * 4 + U * 4 + m["in_total"] * 4 + min(F, m["in_total"]) * 4
                 + F * (4 + 4) + m["node_lists"] * 4 + F * 4 + (0 if last else U * 16))
     if name == "k_selfin":
         return F * (4 + 4 + 4 + 4)
