@@ -805,11 +805,9 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
   uint2 e[RC];
 #pragma unroll
   for (int r = 0; r < RC; r++) e[r] = n + r * BT < q1 - q0 ? qs[q0 + n + r * BT] : make_uint2(UNSET, 0u);
-  auto insert = [&](const uint2 ee) -> uint32_t {
-    const uint32_t h = ht_insert(h_key, ee.x);
-    if (h == UNSET) {
-      atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_BUCKET_FULL);
-    } else if (ee.y & SELF_BIT) {
+  // what an entry leaves in its slot: the self entry its frontier index, an edge entry its position (min)
+  auto record = [&](const uint2 ee, const uint32_t h) {
+    if (ee.y & SELF_BIT) {
       // only the seed layer can hold a node twice
       if (atomicExch(&h_self[h], ee.y & ~SELF_BIT) != UNSET) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
       // graph mode: the self entry is a source of its own slice
@@ -817,30 +815,39 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     } else {
       atomicMin(&h_epos[h], ee.y);
     }
+  };
+  auto insert = [&](const uint2 ee) -> uint32_t {
+    const uint32_t h = ht_insert(h_key, ee.x);
+    if (h == UNSET) {
+      atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_BUCKET_FULL);
+    } else {
+      record(ee, h);
+    }
     return h;
   };
   uint8_t* cflag = a.cflag + (size_t)s * a.ccap;
   auto evaluate = [&](const uint2 ee, const uint32_t h) {
     const uint32_t epos = h_epos[h];
-    const uint32_t g = owner(a, ee.x);
     if (ee.y & SELF_BIT) {
       const uint32_t i = ee.y & ~SELF_BIT;
       const uint32_t c = i * W;
       // k_sample left every flag byte zero: only candidates that are a first occurrence are written
       if (a.graph) {
         const uint32_t fe = epos == c;  // epos already includes the self entry
-        if (fe) cflag[c] = (uint8_t)(fe | (fe << 1) | (g << 2));
+        if (fe) cflag[c] = (uint8_t)(fe | (fe << 1) | (owner(a, ee.x) << 2));
       } else {
         const uint32_t newf = epos > c;  // UNSET compares greater than any position
-        if (newf) cflag[c] = (uint8_t)(newf | (g << 2));
+        if (newf) cflag[c] = (uint8_t)(newf | (owner(a, ee.x) << 2));
       }
       a.firstpos[s * a.fcap + i] = epos;
     } else {
       const uint32_t c = ee.y;
-      const uint32_t self = h_self[h];
       const uint32_t fe = epos == c;
-      const uint32_t newf = a.graph ? fe : (fe && (self == UNSET || (unsigned long long)self * W > c));
-      if (fe) cflag[c] = (uint8_t)(newf | (fe << 1) | (g << 2) | (self != UNSET ? 32u : 0u));
+      if (fe) {
+        const uint32_t self = h_self[h];
+        const uint32_t newf = a.graph ? fe : (self == UNSET || (unsigned long long)self * W > c);
+        cflag[c] = (uint8_t)(newf | (fe << 1) | (owner(a, ee.x) << 2) | (self != UNSET ? 32u : 0u));
+      }
       if (a.graph) a.srcpos[(size_t)s * a.ccap + c] = epos;
     }
   };
