@@ -112,6 +112,9 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
     return out
 
 
+ROW_PAD = 4096   # GEMM row counts are rounded up to a multiple of this (see DistSageConv.finish)
+
+
 class DistSageConv(nn.Module):
     """dist_sageconv.py:8-84: concat(self, aggregated neighbours) -> Linear(2*in, out)."""
 
@@ -143,7 +146,15 @@ class DistSageConv(nn.Module):
         self_h = aggr.GatherRows.apply(x, sl.self_ids_in)
         # (splitting the Linear into two addmm over weight column blocks to avoid this concat was
         # measured 1.5x slower end to end: strided GEMM operands)
-        return self.fc(torch.cat([self_h, neigh], dim=1))
+        cat = torch.cat([self_h, neigh], dim=1)
+        # The row count is different in every minibatch, and hipBLASLt pays a heuristic search for every
+        # GEMM shape it has not seen (80 us instead of 25 us of host time per call, three GEMMs per layer
+        # with backward: profiles/gemm_shape_test.py).  Rounding the rows up makes the shapes repeat.
+        m = cat.shape[0]
+        mp = (m + ROW_PAD - 1) // ROW_PAD * ROW_PAD
+        if mp != m and m >= ROW_PAD:
+            return self.fc(torch.nn.functional.pad(cat, (0, 0, 0, mp - m)))[:m]
+        return self.fc(cat)
 
 
 class DistSAGEModel(nn.Module):
