@@ -214,3 +214,37 @@ def test_extreme_parameters(abi, orc):
         assert_same_sample(e.sample_dict(s), want, what="stream %d of 300" % s)
     assert e.totals()[1] == S
     e.close()
+
+
+def test_full_tile_at_max_fanout(abi, orc):
+    """fanout 255 with more than 256 seeds: a tile holds 256 x 256 = 65536 candidates, the point where
+    k_count's packed 16-bit tile totals could overflow (it switches to unpacked reduction there)."""
+    from cslicer import l0
+    indptr, indices = l0.synth_graph(2000, 300.0, seed=31)
+    perm = np.random.default_rng(6).permutation(2000)
+    for mode in (abi.MODE_STRICT, abi.MODE_GRAPH):
+        e = abi.Engine(indptr, indices, n_parts=2, fanouts=(255,), max_batch=300, n_streams=1, mode=mode)
+        e.submit_seeds([perm[:300]])
+        o = orc.Oracle(indptr, indices, n_parts=2, fanouts=(255,))
+        if mode == abi.MODE_STRICT:
+            assert_same_sample(e.sample_dict(0), o.sample(perm[:300]), what="full tile, fanout 255")
+        else:
+            from test_gpu_graph_mode import assert_same_graph
+            assert_same_graph(e.graph_dict(0), o.sample_graph(perm[:300]), what="full tile, fanout 255, graph mode")
+        e.close()
+
+
+def test_frontier_longer_than_the_register_scan(abi, orc):
+    """A frontier of more than 64 x 12 tiles (196608 nodes): k_scan leaves its register-resident path
+    for the strided loop."""
+    from cslicer import l0
+    n = 320_000
+    indptr, indices = l0.synth_graph(n, 30.0, seed=33)
+    perm = np.random.default_rng(7).permutation(n)
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(20, 20, 2), max_batch=4096, n_streams=1)
+    e.submit_seeds([perm[:4096]])
+    got = e.sample_dict(0)
+    assert max(len(f) for f in got["frontier"]) > 64 * 12 * 256, [len(f) for f in got["frontier"]]
+    assert_same_sample(got, orc.Oracle(indptr, indices, n_parts=4, fanouts=(20, 20, 2)).sample(perm[:4096]),
+                       what="long frontier")
+    e.close()
