@@ -113,6 +113,29 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
 
 
 ROW_PAD = 4096   # GEMM row counts are rounded up to a multiple of this (see DistSageConv.finish)
+SPLIT_K = 32     # the weight-gradient GEMM reduces over the rows in this many independent slabs
+
+
+class _SplitKLinear(torch.autograd.Function):
+    """y = x @ W^T + b for a tall x (rows a multiple of ROW_PAD).  Forward and the input gradient are the
+    library's GEMMs; the WEIGHT gradient, a [out, rows] x [rows, in] product with a 10^5-long reduction and
+    a 256 x 200 result, is what the library runs on ~32 workgroups of a 256-CU chip (0.29 ms per step in the
+    rocprofv3 trace of the training step): it is computed as SPLIT_K batched slabs and summed instead."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ weight if ctx.needs_input_grad[0] else None
+        m = x.shape[0]
+        gw = torch.bmm(gy.view(SPLIT_K, m // SPLIT_K, gy.shape[1]).transpose(1, 2),
+                       x.view(SPLIT_K, m // SPLIT_K, x.shape[1])).sum(0)
+        return gx, gw, gy.sum(0)
 
 
 class DistSageConv(nn.Module):
@@ -152,8 +175,10 @@ class DistSageConv(nn.Module):
         # with backward: profiles/gemm_shape_test.py).  Rounding the rows up makes the shapes repeat.
         m = cat.shape[0]
         mp = (m + ROW_PAD - 1) // ROW_PAD * ROW_PAD
-        if mp != m and m >= ROW_PAD:
-            return self.fc(torch.nn.functional.pad(cat, (0, 0, 0, mp - m)))[:m]
+        if m >= ROW_PAD:
+            if mp != m:
+                cat = torch.nn.functional.pad(cat, (0, 0, 0, mp - m))
+            return _SplitKLinear.apply(cat, self.fc.weight, self.fc.bias)[:m]
         return self.fc(cat)
 
 

@@ -158,3 +158,46 @@ def test_split_parallel_sage_matches_dense_reference(mods, P, fan):
         ids = slices[L - 1][g].in_nodes.cpu().long()
         torch.testing.assert_close(x[g].grad.cpu(), fin.grad[ids], rtol=1e-4, atol=1e-5)
     eng.close()
+
+
+def test_split_k_linear_matches_torch():
+    """splitgnn._SplitKLinear (library GEMMs + slab-wise weight gradient) against torch.nn.functional.linear:
+    forward bit-identical (same addmm), gradients within 1e-4 relative (fp32, different summation order)."""
+    import torch
+    from cslicer import splitgnn
+    torch.manual_seed(3)
+    m, fin, fout = 2 * splitgnn.ROW_PAD, 200, 64
+    x = torch.rand((m, fin), device="cuda", requires_grad=True)
+    w = (torch.rand((fout, fin), device="cuda") - 0.5).requires_grad_(True)
+    b = torch.rand((fout,), device="cuda", requires_grad=True)
+    gy = torch.rand((m, fout), device="cuda")
+    y0 = torch.nn.functional.linear(x, w, b)
+    g0 = torch.autograd.grad(y0, (x, w, b), gy)
+    y1 = splitgnn._SplitKLinear.apply(x, w, b)
+    g1 = torch.autograd.grad(y1, (x, w, b), gy)
+    assert torch.allclose(y0, y1, rtol=1e-6, atol=1e-6)
+    for a_, b_ in zip(g0, g1):
+        assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-3 * float(a_.abs().max()) * 1e-1), float((a_ - b_).abs().max())
+
+
+def test_finish_pads_rows_without_changing_results():
+    """DistSageConv.finish pads the GEMM rows to a multiple of ROW_PAD above ROW_PAD rows: same output rows
+    as the unpadded Linear."""
+    import torch
+    from cslicer import splitgnn
+    torch.manual_seed(4)
+    conv = splitgnn.DistSageConv(32, 16).cuda()
+    m = splitgnn.ROW_PAD + 37
+
+    class S(object):
+        pass
+    sl = S()
+    sl.owned_out_nodes = torch.arange(m, dtype=torch.int32, device="cuda")
+    sl.owned_degree = torch.randint(1, 9, (m,), dtype=torch.int32, device="cuda")
+    sl.self_ids_in = torch.randint(0, m, (m,), dtype=torch.int32, device="cuda")
+    agg = torch.rand((m, 32), device="cuda")
+    x = torch.rand((m, 32), device="cuda")
+    got = conv.finish(sl, agg, x)
+    want = conv.fc(torch.cat([x[sl.self_ids_in.long()], agg / sl.owned_degree[:, None].float()], dim=1))
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
