@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-from . import _abi, splitgnn
+from . import _abi, aggr, splitgnn
 
 
 class Trainer(object):
@@ -54,7 +54,9 @@ class Trainer(object):
         slices = splitgnn.slices_of(self.eng, stream, slot, parts=[self.rank], device=self.dev, meta=meta)
         self.t_slice += time.perf_counter() - t0
         deep = slices[self.L - 1][self.rank]
-        x = self.feat[(deep.in_nodes // self.P).long()]  # gather of owned input features
+        # gather of owned input features (row v // P of the owner v % P), int32 indices, float4 row kernel
+        rows = deep.in_nodes if self.P == 1 else torch.div(deep.in_nodes, self.P, rounding_mode="floor")
+        x = aggr.gather_rows(self.feat, rows)
         t1 = time.perf_counter()
         if self.world > 1:
             logits = self.model.forward_rank(slices, x, self.rank, self.comm, overlap=self.overlap)
