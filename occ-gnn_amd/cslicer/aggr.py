@@ -83,11 +83,18 @@ def spmm_sum_bwd(indptr, indices, grad_out, n_src, rows=None, compact=False, out
     return gx
 
 
-def gather_rows(src, idx):
-    """dst[k] = src[idx[k]] (zero row for idx -1): pull_for_remotes / self_gather."""
+def gather_rows(src, idx, out=None):
+    """dst[k] = src[idx[k]] (zero row for idx -1): pull_for_remotes / self_gather.
+    out: optional destination, [len(idx), H] with unit column stride (rows may be strided: a column
+    block of a wider matrix)."""
     src = _f32(src)
     idx = _i32(idx)
-    dst = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
+    if out is None:
+        dst = torch.empty((idx.numel(), src.shape[1]), dtype=torch.float32, device=src.device)
+    else:
+        dst = out
+        if dst.shape != (idx.numel(), src.shape[1]) or dst.stride(-1) != 1 or dst.dtype != torch.float32:
+            raise ValueError("out must be float32 [len(idx), H] with unit column stride")
     _chk(_lib().csl_gather_rows_f32(_p(src), src.stride(0), _p(idx), idx.numel(), _p(dst), dst.stride(0),
                                     src.shape[1], _stream()), "csl_gather_rows_f32")
     return dst

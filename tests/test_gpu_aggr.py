@@ -201,3 +201,40 @@ def test_finish_pads_rows_without_changing_results():
     want = conv.fc(torch.cat([x[sl.self_ids_in.long()], agg / sl.owned_degree[:, None].float()], dim=1))
     assert got.shape == want.shape
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,fin,relu", [(500, 32, True), (500, 30, False), (4096 + 37, 32, True), (2 * 4096, 100, False)])
+def test_fused_finish_matches_the_op_chain(m, fin, relu):
+    """splitgnn._SageFinish (one autograd node: gathers into the GEMM operand, GEMM, ReLU) against the chain
+    finish() + torch.relu built from the separate ops: forward 1e-5, gradients 1e-4 (slab-wise weight gradient)."""
+    import torch
+    from cslicer import splitgnn
+    torch.manual_seed(m + fin)
+    conv = splitgnn.DistSageConv(fin, 24).cuda()
+    n_x, n_agg = m + 50, m + 20
+
+    class S(object):
+        pass
+    sl = S()
+    sl.owned_out_nodes = torch.randperm(n_agg, device="cuda")[:m].int()
+    sl.owned_degree = torch.randint(0, 9, (m,), dtype=torch.int32, device="cuda")
+    sl.self_ids_in = torch.randperm(n_x, device="cuda")[:m].int()
+    sl.self_ids_in[::7] = -1                      # nodes never sampled as a source: zero self row
+    agg0 = torch.rand((n_agg, fin), device="cuda")
+    x0 = torch.rand((n_x, fin), device="cuda")
+    gy = torch.rand((m, 24), device="cuda")
+    outs = []
+    for fused in (False, True):
+        agg, x = agg0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        conv.zero_grad()
+        if fused:
+            y = conv.finish_fused(sl, agg, x, relu)
+        else:
+            y = conv.finish(sl, agg, x)
+            y = torch.relu(y) if relu else y
+        y.backward(gy)
+        outs.append((y.detach(), agg.grad, x.grad, conv.fc.weight.grad.clone(), conv.fc.bias.grad.clone()))
+    names = ["y", "grad agg", "grad x", "grad W", "grad b"]
+    for nme, a_, b_ in zip(names, outs[0], outs[1]):
+        tol = 1e-5 if nme == "y" else 1e-4
+        assert torch.allclose(a_, b_, rtol=tol, atol=tol * max(1.0, float(a_.abs().max()))), (nme, float((a_ - b_).abs().max()))
