@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--mode", choices=("strict", "graph"), default="strict",
+                    help="strict = the reference's exported lists (headline); graph = real slice CSR, what the trainer consumes")
     ap.add_argument("--slots", type=int, default=3, help="result slots = rounds in flight (engine streams/scratch sets)")
     ap.add_argument("--serial-rounds", action="store_true",
                     help="no overlap of consecutive rounds (profiling: undisturbed per-kernel durations)")
@@ -168,8 +170,9 @@ def main():
     perm = np.random.default_rng(1).permutation(N).astype(np.int64)
     eng_flags = _abi.FLAG_SERIAL_ROUNDS if args.serial_rounds else 0
     NS = args.slots
+    eng_mode = _abi.MODE_GRAPH if args.mode == "graph" else _abi.MODE_STRICT
     eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=NS,
-                      device=device, flags=eng_flags)
+                      device=device, flags=eng_flags, mode=eng_mode)
     eng.set_nodes(perm)
     from cslicer import shard
     n_rounds, n_batches = shard.rounds_per_epoch(N, B, S)  # full rounds only: every step does S minibatches
@@ -240,8 +243,9 @@ def main():
         "iters_per_sec": iters / dt,
         "config": {
             "workload": "products-like synthetic (N=%d, mean degree %g, pareto degrees, seed %d), GraphSAGE fanout %s "
-                        "(layer 0 = seeds' hop), minibatch %d, %d parts (v %% %d), engine-only (sample+slice)"
-                        % (N, args.mean_deg, args.graph_seed, "/".join(map(str, fan)), B, P, P),
+                        "(layer 0 = seeds' hop), minibatch %d, %d parts (v %% %d), engine-only (sample+slice)%s"
+                        % (N, args.mean_deg, args.graph_seed, "/".join(map(str, fan)), B, P, P,
+                           ", graph mode (real slice CSR + boundary lists)" if args.mode == "graph" else ""),
             "streams": S,
             "minibatches_per_step": S,
             "round_overlap": not args.serial_rounds,
@@ -279,7 +283,7 @@ def main():
         }
         tr.close()
         eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=NS,
-                          device=device, flags=eng_flags) if (rank == 0 and not args.no_kernel_timing) else None
+                          device=device, flags=eng_flags, mode=eng_mode) if (rank == 0 and not args.no_kernel_timing) else None
         if eng is not None:
             eng.set_nodes(perm)
             for w in range(args.warmup):
