@@ -12,6 +12,10 @@
  *                             per-GPU means, bipartite.py:98; sums + one division is the
  *                             mathematically intended mean)
  *
+ *   csl_gat_fwd_f32 /         attention aggregation of BASELINE config 5 (GAT).  The reference has only
+ *   csl_gat_bwd_f32           BipartiteGraph.attention_gather (bipartite.py:75-80) and a stub layer
+ *                             (layers/dist_gatconv.py:3-6): "parity unpinned", defined against torch.
+ *
  * All pointers are DEVICE pointers; index arrays are int32 (the slices' device type); `stream`
  * is a hipStream_t.  fp32 throughout.  Returns 0 or a negative CSL_E_* code (cslicer_hip.h).
  */
@@ -45,6 +49,21 @@ int csl_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_
 
 /* x[k, :] /= max(deg[k], 1) */
 int csl_div_rows_f32(float* x, int64_t ldx, const int32_t* deg, int64_t n, int32_t H, void* stream);
+
+/* GAT partial attention over one slice's CSR (sources owned by this part), per destination row r, head h:
+ *   score_e = LeakyReLU(el[src_e,h] + er[r,h]; slope);  m = max_e score_e (-1e30 for an empty row);
+ *   s = sum_e exp(score_e - m);  n[r,h,:] = sum_e exp(score_e - m) * z[src_e,h,:].
+ * el [n_src,H], er/m/s [n_rows,H], z [n_src,H*D], n [n_rows,H*D], all dense row-major, 16-byte aligned;
+ * D % 4 == 0, D <= 256.  The owner of r merges the parts' (m,s,n) and divides. */
+int csl_gat_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, const float* el, const float* er,
+                    const float* z, int32_t H, int32_t D, float slope, float* m_out, float* s_out, float* n_out,
+                    void* stream);
+
+/* Gradients of (s, n) above: g_el [n_src,H] and g_z [n_src,H*D] are ACCUMULATED with fp32 atomics (zero them
+ * first), g_er [n_rows,H] is written.  m_in is the forward's m (a stabiliser, not differentiated). */
+int csl_gat_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, const float* el, const float* er,
+                    const float* z, int32_t H, int32_t D, float slope, const float* m_in, const float* g_s,
+                    const float* g_n, float* g_el, float* g_er, float* g_z, void* stream);
 
 #ifdef __cplusplus
 }

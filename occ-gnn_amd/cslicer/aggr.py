@@ -12,7 +12,7 @@ import torch
 from . import _abi
 
 SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
-           "csl_scatter_add_rows_f32", "csl_div_rows_f32"]
+           "csl_scatter_add_rows_f32", "csl_div_rows_f32", "csl_gat_fwd_f32", "csl_gat_bwd_f32"]
 _ready = False
 
 
@@ -26,6 +26,9 @@ def _lib():
         L.csl_gather_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_scatter_add_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_div_rows_f32.argtypes = [vp, i64, vp, i64, i32, vp]
+        f32 = C.c_float
+        L.csl_gat_fwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
+        L.csl_gat_bwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
         _ready = True
     return L
 
@@ -180,6 +183,41 @@ class GatherMeanRows(torch.autograd.Function):
         gs = torch.zeros((ctx.n_src, g.shape[1]), dtype=torch.float32, device=g.device)
         scatter_add_rows_(gs, idx, g)
         return gs, None, None
+
+
+class GatAggregate(torch.autograd.Function):
+    """Partial edge-softmax aggregation of one slice (csl_gat_fwd_f32 / csl_gat_bwd_f32): returns
+    (m [rows,H], s [rows,H], n [rows,H*D]); m is a stabiliser and is not differentiated (the merged
+    result n/s does not depend on it)."""
+
+    @staticmethod
+    def forward(ctx, el, er, z, indptr, indices, n_rows, H, D, slope):
+        el, er, z = _f32(el).contiguous(), _f32(er).contiguous(), _f32(z).contiguous()
+        indptr, indices = _i32(indptr), _i32(indices)
+        if el.shape != (z.shape[0], H) or er.shape != (n_rows, H) or z.shape[1] != H * D:
+            raise ValueError("el [n_src,H], er [n_rows,H], z [n_src,H*D] expected")
+        dev = z.device
+        m = torch.empty((n_rows, H), dtype=torch.float32, device=dev)
+        s = torch.empty((n_rows, H), dtype=torch.float32, device=dev)
+        n = torch.empty((n_rows, H * D), dtype=torch.float32, device=dev)
+        _chk(_lib().csl_gat_fwd_f32(_p(indptr), _p(indices), n_rows, _p(el), _p(er), _p(z), H, D, slope,
+                                    _p(m), _p(s), _p(n), _stream()), "csl_gat_fwd_f32")
+        ctx.save_for_backward(el, er, z, indptr, indices, m)
+        ctx.cfg = (n_rows, H, D, slope)
+        ctx.mark_non_differentiable(m)
+        return m, s, n
+
+    @staticmethod
+    def backward(ctx, _gm, gs, gn):
+        el, er, z, indptr, indices, m = ctx.saved_tensors
+        n_rows, H, D, slope = ctx.cfg
+        gs, gn = gs.contiguous(), gn.contiguous()
+        g_el = torch.zeros_like(el)
+        g_er = torch.empty_like(er)
+        g_z = torch.zeros_like(z)
+        _chk(_lib().csl_gat_bwd_f32(_p(indptr), _p(indices), n_rows, _p(el), _p(er), _p(z), H, D, slope, _p(m),
+                                    _p(gs), _p(gn), _p(g_el), _p(g_er), _p(g_z), _stream()), "csl_gat_bwd_f32")
+        return g_el, g_er, g_z, None, None, None, None, None, None
 
 
 def attention_gather(indptr, indices, u_in, v_in, n_rows):

@@ -283,6 +283,105 @@ class DistSAGEModel(nn.Module):
         return x
 
 
+
+class DistGATConv(nn.Module):
+    """Multi-head graph attention over the slices (BASELINE config 5).  The reference has no implementation
+    (python/layers/dist_gatconv.py:3-6 is a stub; bipartite.py:75-80 `attention_gather` is the only piece), so
+    the layer is DEFINED here, GATConv-style, and pinned against a dense torch computation ("parity unpinned"
+    by the reference):
+
+        z = W x;  el = <z, a_l>;  er = <z, a_r>   per head
+        alpha(u -> v) = softmax over the sampled in-edges of v of LeakyReLU(el[u] + er[v])
+        out[v] = sum_u alpha(u -> v) z[u] + bias          (a node without sampled neighbours gets the bias)
+
+    Split-parallel form: part g holds z/el of the sources it owns and the edges out of them.  The owner of a
+    destination sends its er to the parts that hold edges into it (the boundary lists, reverse direction), every
+    part computes the partial softmax state (m, s, n) of its local edges in ONE fused HIP pass
+    (aggr.GatAggregate), the partials travel to the owner like SAGE's partial sums and are merged there with the
+    usual log-sum-exp rescaling; out = n / s."""
+
+    def __init__(self, in_feats, out_feats, heads, slope=0.2):
+        super().__init__()
+        self.H, self.D, self.slope = heads, out_feats, slope
+        self.fc = nn.Linear(in_feats, heads * out_feats, bias=False)
+        self.attn_l = nn.Parameter(torch.empty(heads, out_feats))
+        self.attn_r = nn.Parameter(torch.empty(heads, out_feats))
+        self.bias = nn.Parameter(torch.zeros(heads * out_feats))
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_normal_(self.fc.weight, gain=gain)
+        nn.init.xavier_normal_(self.attn_l, gain=gain)
+        nn.init.xavier_normal_(self.attn_r, gain=gain)
+
+    def project(self, x):
+        z = self.fc(x)
+        zv = z.view(-1, self.H, self.D)
+        return z, (zv * self.attn_l).sum(-1), (zv * self.attn_r).sum(-1)
+
+    def forward_parts(self, sl, x):
+        """sl[g]: Slice of part g, x[g]: features of sl[g].in_nodes.  Returns per part the [n_owned, H*D]
+        output rows of the nodes it owns (frontier order)."""
+        parts = sorted(sl.keys())
+        H, D = self.H, self.D
+        proj = {g: self.project(x[g]) for g in parts}
+        # er of the destinations: owned rows from the part's own projection ...
+        er_out = {}
+        for g in parts:
+            e = torch.zeros((sl[g].n_out, H), dtype=torch.float32, device=x[g].device)
+            er_out[g] = e.index_copy(0, sl[g].owned_out_nodes.long(), proj[g][2][sl[g].self_ids_in.long()])
+        er_own = dict(er_out)
+        # ... rows owned by a peer from that peer (boundary lists, reverse direction of the partial sums)
+        for g in parts:
+            for p in parts:
+                if p != g and sl[g].from_ids[p].numel():
+                    er_out[g] = er_out[g].index_copy(0, sl[g].from_ids[p].long(), er_own[p][sl[p].to_ids[g].long()])
+        part = {g: aggr.GatAggregate.apply(proj[g][1], er_out[g], proj[g][0], sl[g].indptr, sl[g].indices,
+                                           sl[g].n_out, H, D, self.slope) for g in parts}
+        out = {}
+        for p in parts:
+            M, S, N = part[p]
+            N = N.view(-1, H, D)
+            for g in parts:
+                if g == p or not sl[p].to_ids[g].numel():
+                    continue
+                idx, src = sl[p].to_ids[g].long(), sl[g].from_ids[p].long()
+                m2, s2, n2 = part[g][0][src], part[g][1][src], part[g][2].view(-1, H, D)[src]
+                Mi = M[idx]
+                Mn = torch.maximum(Mi, m2)
+                a, b = torch.exp(Mi - Mn), torch.exp(m2 - Mn)
+                S = S.index_copy(0, idx, S[idx] * a + s2 * b)
+                N = N.index_copy(0, idx, N[idx] * a.unsqueeze(-1) + n2 * b.unsqueeze(-1))
+                M = M.index_copy(0, idx, Mn)
+            own = sl[p].owned_out_nodes.long()
+            out[p] = (N[own] / S[own].clamp_min(1e-30).unsqueeze(-1)).reshape(-1, H * D) + self.bias
+        return out
+
+
+class DistGATModel(nn.Module):
+    """n_layers DistGATConv: hidden layers concatenate their heads (ELU), the last layer averages them."""
+
+    def __init__(self, in_feats, hidden, n_classes, heads=8, n_layers=3):
+        super().__init__()
+        dims = [in_feats] + [hidden * heads] * (n_layers - 1)
+        # the aggregation kernel moves float4 columns: per-head widths are multiples of 4 (the class
+        # dimension is padded, the extra logits are dropped)
+        self.n_classes = n_classes
+        outs = [hidden] * (n_layers - 1) + [(n_classes + 3) // 4 * 4]
+        self.heads = heads
+        self.convs = nn.ModuleList([DistGATConv(dims[k], outs[k], heads) for k in range(n_layers)])
+
+    def forward_parts(self, slices, feats):
+        L = len(slices)
+        parts = sorted(slices[0].keys())
+        x = {g: feats[g] for g in parts}
+        for k, conv in enumerate(self.convs):
+            x = conv.forward_parts(slices[L - 1 - k], x)
+            if k + 1 < len(self.convs):
+                x = {g: torch.nn.functional.elu(x[g]) for g in parts}
+            else:
+                x = {g: x[g].view(-1, self.heads, conv.D).mean(1)[:, :self.n_classes] for g in parts}
+        return x
+
+
 class _OverlappedAggregate(torch.autograd.Function):
     """local sum-aggregate + boundary exchange + merge of ONE layer on ONE rank, with the
     all-to-all on the communicator's side stream while the rows that never leave the GPU are

@@ -178,6 +178,113 @@ __global__ __launch_bounds__(BLK) void k_div_rows(float* __restrict__ x, long lo
   }
 }
 
+
+// ---- GAT: fused edge-softmax aggregation over one slice's CSR, split-parallel form.
+// For destination row r and head h, over the row's LOCAL edges (sources owned by this part):
+//   score_e = LeakyReLU(el[src_e, h] + er[r, h])        m = max_e score_e
+//   s = sum_e exp(score_e - m)                          n[h, :] = sum_e exp(score_e - m) * z[src_e, h, :]
+// (m, s, n) are the partial softmax state the owner of r merges across parts (log-sum-exp), then out = n / s.
+// One wave per row, a lane owns 4 consecutive feature columns (so D % 4 == 0, D <= 256);
+// rows have <= fanout edges, so both passes stay in cache.  HBM-bound gather of z rows: no MFMA.
+__device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : slope * x; }
+
+__global__ __launch_bounds__(BLK) void k_gat_fwd(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                 long long n_rows, const float* __restrict__ el,
+                                                 const float* __restrict__ er, const float* __restrict__ z, int H, int D,
+                                                 float slope, float* __restrict__ m_out, float* __restrict__ s_out,
+                                                 float* __restrict__ n_out) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int C = H * D;
+  const int lpc = (64 / (D / 4)) * (D / 4);  // lanes per chunk: whole heads only
+  const int e0 = indptr[r], e1 = indptr[r + 1];
+  for (int c0 = 0; c0 < C; c0 += lpc * 4) {
+    const int c = c0 + lane * 4;
+    const bool on = lane < lpc && c < C;
+    const int h = on ? c / D : 0;
+    const float erv = er[r * H + h];
+    float m = -1e30f;
+    for (int e = e0; e < e1; e++) m = fmaxf(m, leaky(el[(long long)indices[e] * H + h] + erv, slope));
+    float s = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = e0; e < e1; e++) {
+      const long long src = indices[e];
+      const float p = expf(leaky(el[src * H + h] + erv, slope) - m);
+      s += p;
+      if (on) {
+        const float4 zv = *reinterpret_cast<const float4*>(z + src * C + c);
+        acc.x += p * zv.x;
+        acc.y += p * zv.y;
+        acc.z += p * zv.z;
+        acc.w += p * zv.w;
+      }
+    }
+    if (on) {
+      *reinterpret_cast<float4*>(n_out + r * C + c) = acc;
+      if (c % D == 0) {
+        m_out[r * H + h] = m;
+        s_out[r * H + h] = s;
+      }
+    }
+  }
+}
+
+// Backward of (s, n) w.r.t. el, er, z (m is a stabiliser: the merged result does not depend on it).
+// g_el and g_z are accumulated with fp32 atomics (caller zeroes them), g_er is written.
+__global__ __launch_bounds__(BLK) void k_gat_bwd(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                 long long n_rows, const float* __restrict__ el,
+                                                 const float* __restrict__ er, const float* __restrict__ z, int H, int D,
+                                                 float slope, const float* __restrict__ m_in,
+                                                 const float* __restrict__ g_s, const float* __restrict__ g_n,
+                                                 float* g_el, float* __restrict__ g_er, float* g_z) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+  if (r >= n_rows) return;
+  const int C = H * D;
+  const int gsz = D / 4;              // lanes of one head
+  const int lpc = (64 / gsz) * gsz;   // lanes per chunk: whole heads only
+  const int gl = lane % gsz;          // position inside the head's lane group
+  const int e0 = indptr[r], e1 = indptr[r + 1];
+  for (int c0 = 0; c0 < C; c0 += lpc * 4) {
+    const int c = c0 + lane * 4;
+    const bool on = lane < lpc && c < C;
+    const int h = on ? c / D : 0;
+    const float erv = er[r * H + h], mh = m_in[r * H + h], gs = g_s[r * H + h];
+    const float4 gn = on ? *reinterpret_cast<const float4*>(g_n + r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float ger = 0.f;
+    for (int e = e0; e < e1; e++) {
+      const long long src = indices[e];
+      const float raw = el[src * H + h] + erv;
+      const float p = expf(leaky(raw, slope) - mh);
+      float dot = 0.f;
+      if (on) {
+        const float4 zv = *reinterpret_cast<const float4*>(z + src * C + c);
+        dot = gn.x * zv.x + gn.y * zv.y + gn.z * zv.z + gn.w * zv.w;
+      }
+      // sum over the head's lane group (any size): segmented tree, then the leader's value for all
+      for (int o = 1; o < gsz; o <<= 1) {
+        const float t = __shfl_down(dot, o);
+        if (gl + o < gsz) dot += t;
+      }
+      dot = __shfl(dot, lane - gl);
+      const float gsc = (gs + dot) * p * (raw > 0.f ? 1.f : slope);
+      if (on) {
+        float* gz = g_z + src * C + c;
+        atomicAdd(gz + 0, p * gn.x);
+        atomicAdd(gz + 1, p * gn.y);
+        atomicAdd(gz + 2, p * gn.z);
+        atomicAdd(gz + 3, p * gn.w);
+        if (c % D == 0) {
+          atomicAdd(g_el + src * H + h, gsc);
+          ger += gsc;
+        }
+      }
+    }
+    if (on && c % D == 0) g_er[r * H + h] = ger;
+  }
+}
+
 int group_for(int H) {
   int q = (H + 3) / 4, g = 1;
   while (g < q && g < 64) g <<= 1;
@@ -255,6 +362,35 @@ int csl_div_rows_f32(float* x, int64_t ldx, const int32_t* deg, int64_t n, int32
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(x, ldx, x, ldx, H);
   DISPATCH_G(G, k_div_rows, n, x, (long long)ldx, deg, (long long)n, (int)H, v);
+  return done();
+}
+
+static int gat_args_ok(const void* a, const void* b, const void* c, int32_t H, int32_t D) {
+  if (H < 1 || D < 4 || D % 4 != 0 || D > 256) return 0;  // a head is at most one wave of float4 lanes
+  return aligned16(a) && aligned16(b) && aligned16(c);
+}
+
+int csl_gat_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, const float* el, const float* er,
+                    const float* z, int32_t H, int32_t D, float slope, float* m_out, float* s_out, float* n_out,
+                    void* stream) {
+  if (n_rows < 0 || !indptr || !er || !m_out || !s_out || !n_out || !gat_args_ok(z, n_out, n_out, H, D))
+    return CSL_E_INVALID;
+  if (n_rows == 0) return CSL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gat_fwd, dim3((unsigned)((n_rows + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, indptr,
+                     indices, (long long)n_rows, el, er, z, (int)H, (int)D, slope, m_out, s_out, n_out);
+  return done();
+}
+
+int csl_gat_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, const float* el, const float* er,
+                    const float* z, int32_t H, int32_t D, float slope, const float* m_in, const float* g_s,
+                    const float* g_n, float* g_el, float* g_er, float* g_z, void* stream) {
+  if (n_rows < 0 || !indptr || !er || !m_in || !g_s || !g_n || !g_er || !gat_args_ok(z, g_n, g_z, H, D))
+    return CSL_E_INVALID;
+  if (n_rows == 0) return CSL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gat_bwd, dim3((unsigned)((n_rows + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, indptr,
+                     indices, (long long)n_rows, el, er, z, (int)H, (int)D, slope, m_in, g_s, g_n, g_el, g_er, g_z);
   return done();
 }
 

@@ -1,0 +1,128 @@
+"""GAT attention aggregation (include/cslicer_aggr.h: csl_gat_fwd_f32 / csl_gat_bwd_f32) and the split-parallel
+DistGATConv / DistGATModel built on it (BASELINE config 5).  The reference has only a stub layer
+(python/layers/dist_gatconv.py:3-6) and `attention_gather` (python/data/bipartite.py:75-80), no goldens:
+"parity unpinned" by the reference; the results are pinned by plain torch fp32 computations of the same
+definition.  Tolerance 1e-5 forward (north_star), 1e-4 on gradients."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from cslicer import _abi, aggr, splitgnn
+    _abi.load()
+    return _abi, aggr, splitgnn
+
+
+def _torch_partial(el, er, z, indptr, indices, n_rows, H, D, slope):
+    """(m, s, n) of the definition in cslicer_aggr.h with index ops; m detached like the kernel's."""
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n_rows, device=z.device), deg)
+    src = indices.long()
+    score = torch.nn.functional.leaky_relu(el[src] + er[rows], slope)                   # [E, H]
+    m = torch.full((n_rows, H), -1e30, device=z.device).scatter_reduce(
+        0, rows[:, None].expand(-1, H), score.detach(), "amax", include_self=True)
+    p = torch.exp(score - m[rows])
+    s = torch.zeros((n_rows, H), device=z.device).index_add(0, rows, p)
+    n = torch.zeros((n_rows, H, D), device=z.device).index_add(0, rows, p[:, :, None] * z[src].view(-1, H, D))
+    return m, s, n.view(n_rows, H * D)
+
+
+@pytest.mark.parametrize("H,D", [(8, 32), (4, 12), (1, 4), (3, 48), (8, 64), (2, 256)])
+def test_gat_partial_aggregate_forward_backward(mods, H, D):
+    _, aggr, _ = mods
+    rng = np.random.default_rng(H * 100 + D)
+    n_rows, n_src = 333, 211
+    deg = rng.integers(0, 12, size=n_rows)
+    deg[::9] = 0                                       # rows without local edges
+    indptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    indices = rng.integers(0, n_src, size=int(indptr[-1]))
+    ip, ix = torch.from_numpy(indptr).int().cuda(), torch.from_numpy(indices).int().cuda()
+    torch.manual_seed(D)
+    leaves = [torch.randn(n_src, H, device="cuda"), torch.randn(n_rows, H, device="cuda"),
+              torch.randn(n_src, H * D, device="cuda")]
+    gs, gn = torch.randn(n_rows, H, device="cuda"), torch.randn(n_rows, H * D, device="cuda")
+    res = []
+    for which in ("hip", "torch"):
+        el, er, z = [t.clone().requires_grad_() for t in leaves]
+        if which == "hip":
+            m, s, n = aggr.GatAggregate.apply(el, er, z, ip, ix, n_rows, H, D, 0.2)
+        else:
+            m, s, n = _torch_partial(el, er, z, ip, ix, n_rows, H, D, 0.2)
+        ((s * gs).sum() + (n * gn).sum()).backward()
+        res.append((m.detach(), s.detach(), n.detach(), el.grad, er.grad, z.grad))
+    for name, a, b in zip(["m", "s", "n", "grad el", "grad er", "grad z"], res[0], res[1]):
+        tol = 1e-5 if name in ("m", "s", "n") else 1e-4
+        torch.testing.assert_close(a, b, rtol=tol, atol=tol * max(1.0, float(b.abs().max())), msg=lambda x: name + ": " + x)
+
+
+def _dense_gat(model, trav, feats):
+    """Unsplit torch fp32 GAT on the same sampled computation graph (CPU, python loops)."""
+    L = len(trav["nbr_counts"])
+    h = feats
+    for k, conv in enumerate(model.convs):
+        l = L - 1 - k
+        fr = trav["frontier"][l]
+        counts, flat = trav["nbr_counts"][l], trav["nbr_flat"][l]
+        z, el, er = conv.project(h)
+        zv = z.view(-1, conv.H, conv.D)
+        rows = []
+        pos = 0
+        for i, nd1 in enumerate(fr):
+            nb = flat[pos + 1:pos + counts[i]]
+            pos += counts[i]
+            nb = torch.as_tensor(nb[nb != nd1]).long()
+            if len(nb):
+                a = torch.softmax(torch.nn.functional.leaky_relu(el[nb] + er[nd1], conv.slope), dim=0)   # [deg, H]
+                rows.append((a[:, :, None] * zv[nb]).sum(0).reshape(-1) + conv.bias)
+            else:
+                rows.append(conv.bias + 0 * z[0])
+        new = torch.zeros(h.shape[0], conv.H * conv.D).index_copy(0, torch.as_tensor(np.asarray(fr)).long(), torch.stack(rows))
+        if k + 1 < len(model.convs):
+            h = torch.nn.functional.elu(new)
+        else:
+            h = new.view(-1, model.heads, conv.D).mean(1)[:, :model.n_classes]
+    return h
+
+
+@pytest.mark.parametrize("P,fan,heads", [(4, (10, 10, 10), 8), (2, (6, 4), 4), (1, (5, 5), 2)])
+def test_split_parallel_gat_matches_dense_reference(mods, P, fan, heads):
+    abi, aggr, sg = mods
+    from cslicer import l0
+    from oracle import oracle as orc
+    torch.manual_seed(1)
+    n, F0, hidden, classes, B = 2500, 20, 8, 7, 48
+    indptr, indices = l0.synth_graph(n, 10.0, seed=6)
+    seeds = np.random.default_rng(3).permutation(n)[:B]
+    eng = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, mode=abi.MODE_GRAPH)
+    eng.submit_seeds([seeds])
+    slices = sg.slices_of(eng)
+    L = len(fan)
+    feats = torch.randn(n, F0)
+    model = sg.DistGATModel(F0, hidden, classes, heads=heads, n_layers=L)
+    with torch.no_grad():
+        for conv in model.convs:
+            conv.bias.normal_(0, 0.1)
+    gm = sg.DistGATModel(F0, hidden, classes, heads=heads, n_layers=L).cuda()
+    gm.load_state_dict(model.state_dict())
+    x = {g: feats[slices[L - 1][g].in_nodes.cpu().long()].cuda().requires_grad_() for g in range(P)}
+    out = gm.forward_parts(slices, x)
+    trav = orc.Oracle(indptr, indices, n_parts=P, fanouts=fan).sample(seeds)
+    fin = feats.clone().requires_grad_()
+    ref = _dense_gat(model, trav, fin)
+    for g in range(P):
+        own = seeds[seeds % P == g]
+        torch.testing.assert_close(out[g].detach().cpu(), ref[own].detach(), rtol=1e-5, atol=1e-5)
+    w = torch.randn(n, classes)
+    (ref[seeds] * w[seeds]).sum().backward()
+    sum((out[g] * w[seeds[seeds % P == g]].cuda()).sum() for g in range(P)).backward()
+    for (na, pa), (nb, pb) in zip(gm.named_parameters(), model.named_parameters()):
+        torch.testing.assert_close(pa.grad.cpu(), pb.grad, rtol=1e-4, atol=1e-5, msg=lambda x: "grad " + na + ": " + x)
+    for g in range(P):
+        ids = slices[L - 1][g].in_nodes.cpu().long()
+        torch.testing.assert_close(x[g].grad.cpu(), fin.grad[ids], rtol=1e-4, atol=1e-5)
+    eng.close()
