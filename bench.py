@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--e2e-multi", action="store_true",
                     help="also run the end-to-end leg when WORLD_SIZE > 1 (boundary all-to-all over RCCL); off by "
                          "default so the slicer scaling runs never depend on it")
+    ap.add_argument("--e2e-model", choices=("sage", "gat"), default="sage",
+                    help="sage: BASELINE configs 1-3 (default); gat: config 5's layer (8 heads, hidden = per-head width)")
+    ap.add_argument("--e2e-heads", type=int, default=8)
     ap.add_argument("--e2e-hidden", type=int, default=256)
     ap.add_argument("--e2e-feat", type=int, default=100)
     ap.add_argument("--e2e-classes", type=int, default=47)
@@ -262,7 +265,8 @@ def main():
         from cslicer.train import Trainer, synthetic_node_data
         feats, labels = synthetic_node_data(N, args.e2e_feat, args.e2e_classes, seed=0)
         tr = Trainer(indptr, indices, feats, labels, args.e2e_classes, rank=rank, world=world, fanouts=fan,
-                     batch=B, streams=8, hidden=args.e2e_hidden, device=device, dist=dist)
+                     batch=B, streams=8, hidden=args.e2e_hidden, device=device, dist=dist,
+                     model=args.e2e_model, heads=args.e2e_heads)
         del feats
         tr.set_nodes(perm)
         tr.run(16)                       # warm-up (allocator, rng window, GEMM heuristics)
@@ -276,8 +280,9 @@ def main():
         out["e2e"] = {
             "iters_per_sec": args.e2e_steps / t_e2e, "ms_per_iter": 1e3 * t_e2e / args.e2e_steps,
             "steps": args.e2e_steps,
-            "config": "split-parallel GraphSAGE fanout %s, batch %d (global), %d part(s) = %d GPU(s), features %d, "
+            "config": "split-parallel %s fanout %s, batch %d (global), %d part(s) = %d GPU(s), features %d, "
                       "hidden %d, classes %d, fp32, Adam; slice+gather+fwd+bwd+step" % (
+                          "GraphSAGE" if args.e2e_model == "sage" else "GAT (%d heads)" % args.e2e_heads,
                           "/".join(map(str, fan)), B, world, world, args.e2e_feat, args.e2e_hidden, args.e2e_classes),
             "scaling": "strong",
         }

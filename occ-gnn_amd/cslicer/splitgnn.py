@@ -125,7 +125,8 @@ class _SplitKLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
-        return torch.addmm(bias, x, weight.t())
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
 
     @staticmethod
     def backward(ctx, gy):
@@ -135,7 +136,7 @@ class _SplitKLinear(torch.autograd.Function):
         m = x.shape[0]
         gw = torch.bmm(gy.view(SPLIT_K, m // SPLIT_K, gy.shape[1]).transpose(1, 2),
                        x.view(SPLIT_K, m // SPLIT_K, x.shape[1])).sum(0)
-        return gx, gw, gy.sum(0)
+        return gx, gw, (gy.sum(0) if ctx.has_bias else None)
 
 
 class _SageFinish(torch.autograd.Function):
@@ -313,9 +314,20 @@ class DistGATConv(nn.Module):
         nn.init.xavier_normal_(self.attn_r, gain=gain)
 
     def project(self, x):
-        z = self.fc(x)
-        zv = z.view(-1, self.H, self.D)
-        return z, (zv * self.attn_l).sum(-1), (zv * self.attn_r).sum(-1)
+        """z = W x and the two attention logits per head.  el = <z, a_l> = x (a_l W)^T: the logits are two
+        [rows, in] x [in, H] GEMMs on x instead of elementwise products and reductions over the wide z."""
+        w = self.fc.weight
+        m = x.shape[0]
+        if m >= ROW_PAD:  # tall operand: shapes that repeat + slab-wise weight gradient (see _SplitKLinear)
+            mp = (m + ROW_PAD - 1) // ROW_PAD * ROW_PAD
+            xp = torch.nn.functional.pad(x, (0, 0, 0, mp - m)) if mp != m else x
+            z = _SplitKLinear.apply(xp, w, None)[:m]
+        else:
+            z = self.fc(x)
+        w3 = w.view(self.H, self.D, -1)
+        wl = (self.attn_l.unsqueeze(-1) * w3).sum(1)  # [H, in]
+        wr = (self.attn_r.unsqueeze(-1) * w3).sum(1)
+        return z, x @ wl.t(), x @ wr.t()
 
     def forward_parts(self, sl, x):
         """sl[g]: Slice of part g, x[g]: features of sl[g].in_nodes.  Returns per part the [n_owned, H*D]

@@ -23,7 +23,8 @@ from . import _abi, aggr, splitgnn
 
 class Trainer(object):
     def __init__(self, indptr, indices, features, labels, n_classes, rank=0, world=1, fanouts=(15, 10, 5),
-                 batch=1024, streams=8, hidden=256, lr=1e-3, device=0, dist=None, seed=0, overlap=False):
+                 batch=1024, streams=8, hidden=256, lr=1e-3, device=0, dist=None, seed=0, overlap=False,
+                 model="sage", heads=8):
         """features: float32 [N, F] (host, the rank keeps only the rows it owns); labels int64 [N]."""
         self.rank, self.world, self.dist = rank, world, dist
         self.P = world
@@ -37,7 +38,15 @@ class Trainer(object):
         self.feat = torch.from_numpy(np.ascontiguousarray(features[own])).to(self.dev)   # row v // P of owner v % P
         self.labels = torch.from_numpy(np.ascontiguousarray(labels[own])).to(self.dev)
         torch.manual_seed(seed)      # identical replicated weights on every rank
-        self.model = splitgnn.DistSAGEModel(features.shape[1], hidden, n_classes, n_layers=self.L).to(self.dev)
+        if model == "sage":
+            self.model = splitgnn.DistSAGEModel(features.shape[1], hidden, n_classes, n_layers=self.L).to(self.dev)
+        elif model == "gat":
+            if world != 1:
+                raise NotImplementedError("the GAT layers run all parts in one process so far (DESIGN.md 8f)")
+            self.model = splitgnn.DistGATModel(features.shape[1], hidden, n_classes, heads=heads,
+                                               n_layers=self.L).to(self.dev)
+        else:
+            raise ValueError("model must be 'sage' or 'gat'")
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
         self.comm = splitgnn.DistComm(device=self.dev) if world > 1 else None
         self.overlap = overlap

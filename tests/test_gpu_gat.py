@@ -68,8 +68,9 @@ def _dense_gat(model, trav, feats):
         l = L - 1 - k
         fr = trav["frontier"][l]
         counts, flat = trav["nbr_counts"][l], trav["nbr_flat"][l]
-        z, el, er = conv.project(h)
+        z = h @ conv.fc.weight.t()                       # the definition, not the layer's own project()
         zv = z.view(-1, conv.H, conv.D)
+        el, er = (zv * conv.attn_l).sum(-1), (zv * conv.attn_r).sum(-1)
         rows = []
         pos = 0
         for i, nd1 in enumerate(fr):
