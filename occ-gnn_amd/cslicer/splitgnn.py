@@ -368,6 +368,41 @@ class DistGATConv(nn.Module):
         return out
 
 
+    def _forward_rank(self, sl, x, comm):
+        """One part per process (DistGATConv.forward_rank): two boundary exchanges per layer."""
+        g, P, H, D = sl.part, sl.n_parts, self.H, self.D
+        z, el, er = self.project(x)
+        er_out = torch.zeros((sl.n_out, H), dtype=torch.float32, device=x.device)
+        er_out = er_out.index_copy(0, sl.owned_out_nodes.long(), er[sl.self_ids_in.long()])
+        # 1) owners -> holders of boundary edges: er of the destinations (reverse direction of the lists)
+        send = [er_out[sl.to_ids[p].long()] if p != g and sl.to_ids[p].numel() else None for p in range(P)]
+        recv, tie = comm.all_to_all(send, [0 if p == g else sl.from_ids[p].numel() for p in range(P)], H)
+        er_out = er_out + tie
+        for p in range(P):
+            if recv[p] is not None:
+                er_out = er_out.index_copy(0, sl.from_ids[p].long(), recv[p])
+        M, S, N = aggr.GatAggregate.apply(el, er_out, z, sl.indptr, sl.indices, sl.n_out, H, D, self.slope)
+        # 2) holders -> owners: the partial softmax state (m | s | n) of the boundary rows
+        packed = torch.cat([M, S, N], dim=1)
+        send = [packed[sl.from_ids[p].long()] if p != g and sl.from_ids[p].numel() else None for p in range(P)]
+        recv, tie = comm.all_to_all(send, [0 if p == g else sl.to_ids[p].numel() for p in range(P)], 2 * H + H * D)
+        S = S + tie
+        N = N.view(-1, H, D)
+        for p in range(P):
+            if recv[p] is None:
+                continue
+            idx = sl.to_ids[p].long()
+            m2, s2, n2 = recv[p][:, :H].detach(), recv[p][:, H:2 * H], recv[p][:, 2 * H:].reshape(-1, H, D)
+            Mi = M[idx]
+            Mn = torch.maximum(Mi, m2)
+            a, b = torch.exp(Mi - Mn), torch.exp(m2 - Mn)
+            S = S.index_copy(0, idx, S[idx] * a + s2 * b)
+            N = N.index_copy(0, idx, N[idx] * a.unsqueeze(-1) + n2 * b.unsqueeze(-1))
+            M = M.index_copy(0, idx, Mn)
+        own = sl.owned_out_nodes.long()
+        return (N[own] / S[own].clamp_min(1e-30).unsqueeze(-1)).reshape(-1, H * D) + self.bias
+
+
 class DistGATModel(nn.Module):
     """n_layers DistGATConv: hidden layers concatenate their heads (ELU), the last layer averages them."""
 
@@ -391,6 +426,18 @@ class DistGATModel(nn.Module):
                 x = {g: torch.nn.functional.elu(x[g]) for g in parts}
             else:
                 x = {g: x[g].view(-1, self.heads, conv.D).mean(1)[:, :self.n_classes] for g in parts}
+        return x
+
+    def forward_rank(self, slices, feat, rank, comm):
+        """One part per process: `comm` (DistComm) carries the two exchanges of every layer over RCCL."""
+        L = len(slices)
+        x = feat
+        for k, conv in enumerate(self.convs):
+            x = conv._forward_rank(slices[L - 1 - k][rank], x, comm)
+            if k + 1 < len(self.convs):
+                x = torch.nn.functional.elu(x)
+            else:
+                x = x.view(-1, self.heads, conv.D).mean(1)[:, :self.n_classes]
         return x
 
 

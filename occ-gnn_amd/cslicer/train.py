@@ -38,11 +38,10 @@ class Trainer(object):
         self.feat = torch.from_numpy(np.ascontiguousarray(features[own])).to(self.dev)   # row v // P of owner v % P
         self.labels = torch.from_numpy(np.ascontiguousarray(labels[own])).to(self.dev)
         torch.manual_seed(seed)      # identical replicated weights on every rank
+        self.kind = model
         if model == "sage":
             self.model = splitgnn.DistSAGEModel(features.shape[1], hidden, n_classes, n_layers=self.L).to(self.dev)
         elif model == "gat":
-            if world != 1:
-                raise NotImplementedError("the GAT layers run all parts in one process so far (DESIGN.md 8f)")
             self.model = splitgnn.DistGATModel(features.shape[1], hidden, n_classes, heads=heads,
                                                n_layers=self.L).to(self.dev)
         else:
@@ -68,7 +67,10 @@ class Trainer(object):
         x = aggr.gather_rows(self.feat, rows)
         t1 = time.perf_counter()
         if self.world > 1:
-            logits = self.model.forward_rank(slices, x, self.rank, self.comm, overlap=self.overlap)
+            if self.kind == "gat":
+                logits = self.model.forward_rank(slices, x, self.rank, self.comm)
+            else:
+                logits = self.model.forward_rank(slices, x, self.rank, self.comm, overlap=self.overlap)
         else:
             logits = self.model.forward_parts(slices, {0: x})[0]
         top = slices[0][self.rank]

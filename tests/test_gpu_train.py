@@ -45,7 +45,7 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, q, overlap=False):
+def _rank_main(rank, world, port, q, overlap=False, kind="sage"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "occ-gnn_amd"))
@@ -58,7 +58,7 @@ def _rank_main(rank, world, port, q, overlap=False):
     from test_gpu_train import _task
     indptr, indices, feats, labels, perm = _task()
     t = Trainer(indptr, indices, feats, labels, 5, rank=rank, world=world, fanouts=(10, 5), batch=128, streams=2,
-                hidden=16, lr=1e-2, dist=dist, overlap=overlap)
+                hidden=16, lr=1e-2, dist=dist, overlap=overlap, model=kind, heads=2)
     t.set_nodes(perm)
     losses = t.run(4)
     tl = torch.tensor(losses, dtype=torch.float64)
@@ -70,15 +70,16 @@ def _rank_main(rank, world, port, q, overlap=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [False, True], ids=["sequential", "side-stream-overlap"])
-def test_two_ranks_match_single_process_two_parts(overlap):
+@pytest.mark.parametrize("overlap,kind", [(False, "sage"), (True, "sage"), (False, "gat")],
+                         ids=["sequential", "side-stream-overlap", "gat"])
+def test_two_ranks_match_single_process_two_parts(overlap, kind):
     import torch.multiprocessing as mp
     from cslicer import _abi, splitgnn
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, overlap)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, overlap, kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
@@ -92,7 +93,10 @@ def test_two_ranks_match_single_process_two_parts(overlap):
                       mode=_abi.MODE_GRAPH)
     eng.set_nodes(perm)
     torch.manual_seed(0)
-    model = splitgnn.DistSAGEModel(feats.shape[1], 16, 5, n_layers=2).to(dev)
+    if kind == "gat":
+        model = splitgnn.DistGATModel(feats.shape[1], 16, 5, heads=2, n_layers=2).to(dev)
+    else:
+        model = splitgnn.DistSAGEModel(feats.shape[1], 16, 5, n_layers=2).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-2)
     ft, lt = torch.from_numpy(feats).to(dev), torch.from_numpy(labels).to(dev)
     ref_losses = []
