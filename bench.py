@@ -327,16 +327,19 @@ def main():
             }
             # HBM traffic of the same kernel from the committed rocprofv3 PMC passes
             # (profiles/<LATEST>/pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
-            # command at the same stream count; KiB, raw: MI355X_MICROARCH.md's x2 FETCH correction
-            # applies to wide coalesced streams only, this kernel's reads are narrow)
+            # command at the same stream count; KiB)
             try:
                 latest = open(os.path.join(ROOT, "profiles", "LATEST")).read().strip()
                 pmc = json.load(open(os.path.join(ROOT, "profiles", latest, "pmc.json")))
                 bj = json.loads(open(os.path.join(ROOT, "profiles", latest, "bench_fetch.json")).read())
                 if bj["config"]["streams"] == S and dom in pmc["calls"]:
                     calls = pmc["calls"][dom]
-                    out["roofline"]["traffic"] = 1024.0 * (pmc["fetch_KiB_sum"][dom] + pmc["write_KiB_sum"][dom]) / calls
-                    out["roofline"]["traffic_source"] = "profiles/%s/pmc.json (FETCH_SIZE raw + WRITE_SIZE)" % latest
+                    # FETCH_SIZE = TCC_EA0_RDREQ x 64 B; a separate PMC pass (profiles/pmc_rdsize.sh) shows that
+                    # > 99.8 % of this path's read requests are 128-B requests, gathers included, so the bytes
+                    # actually fetched are 2 x FETCH_SIZE for every kernel (the guide's gfx950 correction)
+                    out["roofline"]["traffic"] = 1024.0 * (2.0 * pmc["fetch_KiB_sum"][dom] + pmc["write_KiB_sum"][dom]) / calls
+                    out["roofline"]["traffic_source"] = ("profiles/%s/pmc.json (2 x FETCH_SIZE + WRITE_SIZE; all read "
+                                                         "requests are 128 B: profiles/pmc_rdsize.sh)" % latest)
             except Exception:
                 pass
             out["kernels"] = per_kernel

@@ -53,9 +53,10 @@ def main():
         f.write("Command: `profiles/run_profiles.sh` (bench.py --steps 20 --warmup 5 --no-cpu-baseline "
                 "--no-kernel-timing --serial-rounds --e2e-steps 0; three separate runs: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE).\n\n")
         f.write("FETCH_SIZE / WRITE_SIZE are rocprofv3's raw values in KiB, summed over the launches of the run "
-                "(25 rounds x 3 layers = 75 launches per slicer kernel). MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of "
-                "the bytes of a wide coalesced stream (x2 correction); narrow random gathers are uncalibrated, so the "
-                "raw value is a lower bound and 2x raw an upper bound. WRITE_SIZE is exact for wide stores.\n\n")
+                "(25 rounds x 3 layers = 75 launches per slicer kernel). FETCH_SIZE = TCC_EA0_RDREQ x 64 B; "
+                "profiles/pmc_rdsize.sh shows > 99.8 % of every kernel's read requests are 128-B requests (random "
+                "gathers pull whole lines too), so the bytes fetched are 2 x the raw value below "
+                "(MI355X_MICROARCH.md's gfx950 correction). WRITE_SIZE is exact (64-B write requests).\n\n")
         f.write("| kernel | calls | total ms | avg us | max us | % | FETCH_SIZE MiB/launch (raw) | WRITE_SIZE MiB/launch |\n")
         f.write("|---|---|---|---|---|---|---|---|\n")
         for r in rows:
