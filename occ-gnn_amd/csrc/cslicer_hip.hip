@@ -18,7 +18,8 @@
 //   rng word of (i,j)   = base + fanout * #{i' < i : deg(i') >= fanout} + j
 //
 // HBM layout (all device memory, per engine):
-//   rowinfo  u64[N]      (row offset << 24) | degree     one 8-B gather per node
+//   off32    u32[N+1]    row offsets (E < 2^32)          one gather per node (else rowinfo u64[N]:
+//                                                       (row offset << 24) | degree)
 //   indices  u32[E]      CSR neighbours (ids < 2^31)
 //   wl       u8[N]       owner part (absent => v % P)
 //   rng ring u32[2^k]    mt19937 outputs, absolute position & mask
@@ -99,7 +100,8 @@ const char* const kKernelNames[CSL_NUM_KERNELS] = {"k_seeds",   "k_degree", "k_s
 // Everything a layer's kernels need; passed by value.
 struct LArgs {
   // graph
-  const unsigned long long* rowinfo;
+  const unsigned long long* rowinfo;  // u64[N]: (row offset << 24) | degree        (graphs with E >= 2^32)
+  const uint32_t* off32;              // u32[N+1]: row offsets (E < 2^32): half the table, more of it in L2
   const uint32_t* indices;
   const uint8_t* wl;
   uint32_t N, P;
@@ -152,6 +154,16 @@ constexpr uint32_t SELF_BIT = 0x80000000u;
 
 __device__ __forceinline__ uint32_t owner(const LArgs& a, uint32_t v) {
   return a.wl ? (uint32_t)a.wl[v] : (v % a.P);
+}
+// row offset and degree of node v, in ninfo's packed form (the gather of slicer.cpp:8-9).  With 32-bit
+// offsets the lookup table is 4 B per node instead of 8: the random gathers of a layer touch the same
+// number of entries but a line holds twice as many and more of the table stays in the 4 MiB L2s.
+__device__ __forceinline__ unsigned long long row_lookup(const LArgs& a, uint32_t v) {
+  if (a.off32) {
+    const uint32_t lo = a.off32[v], hi = a.off32[v + 1];
+    return ((unsigned long long)lo << 24) | (unsigned long long)(hi - lo);
+  }
+  return a.rowinfo[v];
 }
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ uint32_t div_w(const LArgs& a, uint32_t c) {
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(TN) void k_degree(LArgs a) {
     for (int j = 0; j < 4; j++) v[j] = i0 + j < F ? a.fr_in[s * a.fr_in_stride + i0 + j] : UNSET;
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (v[j] != UNSET) ri[j] = a.rowinfo[v[j]];
+      if (v[j] != UNSET) ri[j] = row_lookup(a, v[j]);
 #pragma unroll
     for (int j = 0; j < 4; j++)
       if (v[j] != UNSET) a.ninfo[s * a.fcap + i0 + j] = ri[j];
@@ -1061,7 +1073,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
         if (p < nf_cap) {
           fr_out[p] = val;
           // the next layer's row lookup rides on this pass (slicer.cpp:8-9)
-          if (!a.last) ninfo[p] = a.rowinfo[val];
+          if (!a.last) ninfo[p] = row_lookup(a, val);
         }
       }
 #ifndef CSL_ABLATE_EMIT_IN
@@ -1358,6 +1370,11 @@ __global__ void k_pack_rows(const long long* indptr, unsigned long long* rowinfo
     rowinfo[i] = (o << DEG_BITS) | d;
   }
 }
+__global__ void k_pack_off32(const long long* indptr, uint32_t* off32, size_t n1) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n1; i += stride) off32[i] = (uint32_t)indptr[i];
+}
 __global__ void k_pack_indices(const long long* src, uint32_t* dst, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1414,6 +1431,7 @@ struct csl_engine {
   std::vector<char> desc_inflight;
   // graph
   unsigned long long* rowinfo = nullptr;
+  uint32_t* off32 = nullptr;
   uint32_t* indices = nullptr;
   uint8_t* wl = nullptr;
   // node order
@@ -1709,6 +1727,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     LArgs a;
     memset(&a, 0, sizeof(a));
     a.rowinfo = e->rowinfo;
+    a.off32 = e->off32;
     a.indices = e->indices;
     a.wl = e->wl;
     a.N = e->N;
@@ -1860,7 +1879,7 @@ void csl_destroy(csl_engine* e) {
     hipEventDestroy(te.b);
   }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
-  void* ptrs[] = {e->rowinfo, e->indices, e->wl,      e->nodes, e->seedbuf, e->ring,  e->mt_state, e->rngpos,
+  void* ptrs[] = {e->rowinfo, e->off32, e->indices, e->wl,      e->nodes, e->seedbuf, e->ring,  e->mt_state, e->rngpos,
                   e->rngbase, e->ninfo,   e->hasedge, e->selfpos, e->firstpos, e->cand, e->cflag, e->crank,
                   e->queue,   e->nbk,     e->bcnt,    e->bcur,    e->tcnt,     e->fsize, e->meta, e->desc_dev,
                   e->ecnt,    e->srcpos,  e->acc};
@@ -1904,7 +1923,9 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   HIPCHECK(hipEventCreateWithFlags(&e->chain_event, hipEventDisableTiming));
   const size_t N = e->N;
   // ---- graph upload + packing (int64 CSR -> rowinfo / u32 indices)
-  DMALLOC(e->rowinfo, N);
+  const bool small_offsets = e->E < (1ull << 32) && !getenv("CSLICER_ROWINFO64");  // (env: force the 8-byte table)
+  if (small_offsets) DMALLOC(e->off32, N + 1);
+  else DMALLOC(e->rowinfo, N);
   DMALLOC(e->indices, e->E);
   {
     long long* tmp = nullptr;
@@ -1914,7 +1935,8 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
     if (r != hipSuccess) return fail(CSL_E_NOMEM, "staging hipMalloc failed: %s", hipGetErrorString(r));
     hipError_t er = hipMemcpy(tmp, cfg->indptr, (N + 1) * sizeof(long long), hipMemcpyHostToDevice);
     if (er == hipSuccess) {
-      hipLaunchKernelGGL(k_pack_rows, dim3(1024), dim3(256), 0, e->stream, tmp, e->rowinfo, N);
+      if (small_offsets) hipLaunchKernelGGL(k_pack_off32, dim3(1024), dim3(256), 0, e->stream, tmp, e->off32, N + 1);
+      else hipLaunchKernelGGL(k_pack_rows, dim3(1024), dim3(256), 0, e->stream, tmp, e->rowinfo, N);
       er = hipStreamSynchronize(e->stream);
     }
     for (size_t o = 0; er == hipSuccess && o < e->E; o += chunk) {

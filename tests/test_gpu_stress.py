@@ -248,3 +248,21 @@ def test_frontier_longer_than_the_register_scan(abi, orc):
     assert_same_sample(got, orc.Oracle(indptr, indices, n_parts=4, fanouts=(20, 20, 2)).sample(perm[:4096]),
                        what="long frontier")
     e.close()
+
+
+def test_both_row_lookup_tables(abi, orc, monkeypatch):
+    """Graphs with fewer than 2^32 edges use a 32-bit offset table for the row lookups, larger ones the packed
+    64-bit (offset, degree) table; CSLICER_ROWINFO64 forces the latter so that both paths stay tested."""
+    from cslicer import l0
+    indptr, indices = l0.synth_graph(5000, 25.0, seed=41)
+    perm = np.random.default_rng(9).permutation(5000)
+    want = orc.Oracle(indptr, indices, n_parts=4, fanouts=(10, 5, 5)).sample(perm[:200])
+    for force64 in (False, True):
+        if force64:
+            monkeypatch.setenv("CSLICER_ROWINFO64", "1")
+        else:
+            monkeypatch.delenv("CSLICER_ROWINFO64", raising=False)
+        e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 5, 5), max_batch=200, n_streams=1)
+        e.submit_seeds([perm[:200]])
+        assert_same_sample(e.sample_dict(0), want, what="row lookup table, 64-bit=%s" % force64)
+        e.close()
