@@ -56,9 +56,9 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--e2e-steps", type=int, default=64,
                     help="end-to-end training minibatches for the secondary iters/s figure (0 = skip)")
-    ap.add_argument("--e2e-multi", action="store_true",
-                    help="also run the end-to-end leg when WORLD_SIZE > 1 (boundary all-to-all over RCCL); off by "
-                         "default so the slicer scaling runs never depend on it")
+    ap.add_argument("--no-e2e-multi", action="store_true", help="several GPUs: skip the split-parallel training leg")
+    ap.add_argument("--e2e-timeout", type=float, default=180.0, help="several GPUs: watchdog of the e2e leg, seconds")
+    ap.add_argument("--e2e-multi", action="store_true", help="(default now; kept for older command lines)")
     ap.add_argument("--e2e-model", choices=("sage", "gat"), default="sage",
                     help="sage: BASELINE configs 1-3 (default); gat: config 5's layer (8 heads, hidden = per-head width)")
     ap.add_argument("--e2e-heads", type=int, default=8)
@@ -259,9 +259,7 @@ def main():
     }
 
     # ---- end-to-end minibatch rate: slice + feature gather + forward/backward + Adam, one part per GPU
-    if args.e2e_steps > 0 and (world == 1 or args.e2e_multi):
-        eng.close()
-        eng = None
+    def e2e_leg():
         from cslicer.train import Trainer, synthetic_node_data
         feats, labels = synthetic_node_data(N, args.e2e_feat, args.e2e_classes, seed=0)
         tr = Trainer(indptr, indices, feats, labels, args.e2e_classes, rank=rank, world=world, fanouts=fan,
@@ -277,7 +275,8 @@ def main():
         torch.cuda.synchronize()
         barrier()
         t_e2e = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)
-        out["e2e"] = {
+        tr.close()
+        return {
             "iters_per_sec": args.e2e_steps / t_e2e, "ms_per_iter": 1e3 * t_e2e / args.e2e_steps,
             "steps": args.e2e_steps,
             "config": "split-parallel %s fanout %s, batch %d (global), %d part(s) = %d GPU(s), features %d, "
@@ -286,14 +285,6 @@ def main():
                           "/".join(map(str, fan)), B, world, world, args.e2e_feat, args.e2e_hidden, args.e2e_classes),
             "scaling": "strong",
         }
-        tr.close()
-        eng = _abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=NS,
-                          device=device, flags=eng_flags, mode=eng_mode) if (rank == 0 and not args.no_kernel_timing) else None
-        if eng is not None:
-            eng.set_nodes(perm)
-            for w in range(args.warmup):
-                run_round(w)
-            eng.sync()
 
     if rank == 0:
         # ---- per-kernel HIP-event timing pass (engine's own stream) for the roofline
@@ -407,9 +398,41 @@ def main():
                     }
                 except Exception as ex:  # the calibration is optional evidence, never fatal
                     out["cpu_baseline"]["reference_calibration"] = {"error": repr(ex)[:200]}
-        print(json.dumps(out))
     if eng is not None:
         eng.close()
+        eng = None
+    # The e2e leg runs LAST, and on several GPUs under a watchdog: its RCCL exchange (all_to_all_single per
+    # layer + gradient all-reduce) has only been rehearsed over gloo in this round, and a collective that never
+    # completes must not take the slicer's result with it.  Rank 0 then prints the line without an e2e rate.
+    if args.e2e_steps > 0 and (world == 1 or not args.no_e2e_multi):
+        if world == 1:
+            out["e2e"] = e2e_leg()
+        else:
+            import threading
+            finished = threading.Event()
+
+            def watchdog():
+                if not finished.wait(args.e2e_timeout):
+                    if rank == 0:
+                        out["e2e"] = {"error": "the %d-GPU e2e leg did not finish within %.0f s" % (world, args.e2e_timeout)}
+                        sys.stdout.write(json.dumps(out) + "\n")
+                        sys.stdout.flush()
+                    os._exit(0)
+
+            threading.Thread(target=watchdog, daemon=True).start()
+            try:
+                res = e2e_leg()
+                if rank == 0:
+                    out["e2e"] = res
+            except Exception as ex:  # this rank leaves; the others' watchdogs release them
+                if rank == 0:
+                    out["e2e"] = {"error": repr(ex)[:300]}
+                    sys.stdout.write(json.dumps(out) + "\n")
+                    sys.stdout.flush()
+                os._exit(0)
+            finished.set()
+    if rank == 0:
+        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
