@@ -83,12 +83,17 @@ class Trainer(object):
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         if self.world > 1:
-            flat = torch.cat([p.grad.reshape(-1) for p in self.model.parameters()])
+            # (a rank whose share of the minibatch produced no gradient for a parameter still takes part)
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                              for p in self.model.parameters()])
             self.dist.all_reduce(flat)                    # replicated weights: sum of per-rank gradients
             o = 0
             for p in self.model.parameters():
                 n = p.numel()
-                p.grad.copy_(flat[o:o + n].view_as(p))
+                if p.grad is None:
+                    p.grad = flat[o:o + n].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[o:o + n].view_as(p))
                 o += n
         self.opt.step()
         self.steps_done += 1
