@@ -800,6 +800,11 @@ __device__ __forceinline__ uint32_t ht_insert(uint32_t* h_key, uint32_t val) {
 #endif
 constexpr int BPB = CSL_BPB;  // buckets a block resolves one after the other; the next one's entries are in flight meanwhile
 
+// HAS_WL: owner parts come from the workload table (a load) instead of v % P.  The kernel is specialised on it
+// because a load that MAY be pending in a register makes the compiler wait for the whole memory counter --
+// i.e. for the acknowledgement of every earlier scattered flag store -- before each next store: that wait,
+// not LDS or the stores themselves, was most of this kernel's time (8 us per bucket).
+template <bool HAS_WL>
 __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
   uint32_t bx, s;
   if (!xcd_block(a, bx, s)) return;
@@ -838,43 +843,49 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     return h;
   };
   uint8_t* cflag = a.cflag + (size_t)s * a.ccap;
-  auto evaluate = [&](const uint2 ee, const uint32_t h) {
-    const uint32_t epos = h_epos[h];
+  auto part_of = [&](const uint32_t v) -> uint32_t { return HAS_WL ? (uint32_t)a.wl[v] : (v % a.P); };
+  // what an entry learns from its slot (epos = first edge position of the node, self = its frontier index);
+  // g = owner part of the node
+  auto judge = [&](const uint2 ee, const uint32_t epos, const uint32_t self, const uint32_t g) {
     if (ee.y & SELF_BIT) {
       const uint32_t i = ee.y & ~SELF_BIT;
       const uint32_t c = i * W;
       // k_sample left every flag byte zero: only candidates that are a first occurrence are written
       if (a.graph) {
         const uint32_t fe = epos == c;  // epos already includes the self entry
-        if (fe) cflag[c] = (uint8_t)(fe | (fe << 1) | (owner(a, ee.x) << 2));
+        if (fe) cflag[c] = (uint8_t)(fe | (fe << 1) | (g << 2));
       } else {
         const uint32_t newf = epos > c;  // UNSET compares greater than any position
-        if (newf) cflag[c] = (uint8_t)(newf | (owner(a, ee.x) << 2));
+        if (newf) cflag[c] = (uint8_t)(newf | (g << 2));
       }
       a.firstpos[s * a.fcap + i] = epos;
     } else {
       const uint32_t c = ee.y;
       const uint32_t fe = epos == c;
       if (fe) {
-        const uint32_t self = h_self[h];
         const uint32_t newf = a.graph ? fe : (self == UNSET || (unsigned long long)self * W > c);
-        cflag[c] = (uint8_t)(newf | (fe << 1) | (owner(a, ee.x) << 2) | (self != UNSET ? 32u : 0u));
+        cflag[c] = (uint8_t)(newf | (fe << 1) | (g << 2) | (self != UNSET ? 32u : 0u));
       }
       if (a.graph) a.srcpos[(size_t)s * a.ccap + c] = epos;
     }
   };
+  auto evaluate = [&](const uint2 ee, const uint32_t h) { judge(ee, h_epos[h], h_self[h], part_of(ee.x)); };
   for (int j = 0; j < BPB; j++, b++) {
     if (b >= nbk) break;  // block-uniform
     const uint2* q = qs + q0;
     const uint32_t cnt = q1 - q0;
-    // the next bucket's first entries are requested before this one is resolved
+    // The next bucket's first entries are requested before this one is resolved.  The loads are issued
+    // UNCONDITIONALLY (idle lanes and the last bucket re-read element 0): a load inside a branch would make
+    // the compiler wait for the whole memory counter at the next use of any loaded register, prefetch included.
     uint2 en[RC];
-    uint32_t q1n = q1;
     const bool more = j + 1 < BPB && b + 1 < nbk;
-    if (more) {
-      q1n = off[b + 2];
+    const uint32_t q1n = off[more ? b + 2 : b + 1];
 #pragma unroll
-      for (int r = 0; r < RC; r++) en[r] = n + r * BT < q1n - q1 ? qs[q1 + n + r * BT] : make_uint2(UNSET, 0u);
+    for (int r = 0; r < RC; r++) {
+      const uint32_t k = n + r * BT;
+      const bool ok = more && k < q1n - q1;
+      en[r] = qs[ok ? q1 + k : 0u];
+      if (!ok) en[r] = make_uint2(UNSET, 0u);
     }
     {
       // 16-byte LDS stores: 6 per thread instead of 24
@@ -891,9 +902,15 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     for (int r = 0; r < RC; r++) hs[r] = e[r].x != UNSET ? insert(e[r]) : UNSET;
     for (uint32_t k = n + RC * BT; k < cnt; k += BT) insert(q[k]);
     __syncthreads();
+    {
+      // owner parts first (with a workload table these are loads: all requested before the first store)
+      uint32_t og[RC];
 #pragma unroll
-    for (int r = 0; r < RC; r++)
-      if (hs[r] != UNSET) evaluate(e[r], hs[r]);
+      for (int r = 0; r < RC; r++) og[r] = hs[r] != UNSET ? part_of(e[r].x) : 0u;
+#pragma unroll
+      for (int r = 0; r < RC; r++)
+        if (hs[r] != UNSET) judge(e[r], h_epos[hs[r]], h_self[hs[r]], og[r]);
+    }
     for (uint32_t k = n + RC * BT; k < cnt; k += BT) {
       const uint2 ee = q[k];
       const uint32_t h = ht_find(h_key, ee.x);
@@ -1827,7 +1844,8 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     }
     {
       Timed t(e, KN_BUCKET, st);
-      hipLaunchKernelGGL(k_bucket, grid_bucket, dim3(BT), 0, st, a);
+      if (a.wl) hipLaunchKernelGGL(k_bucket<true>, grid_bucket, dim3(BT), 0, st, a);
+      else hipLaunchKernelGGL(k_bucket<false>, grid_bucket, dim3(BT), 0, st, a);
     }
     {
       Timed t(e, KN_COUNT, st);
