@@ -48,3 +48,44 @@ def test_rocprof_stats_agree_with_bench_kernel_time():
     row = [r for r in rows if ("::" + dom + "(") in r["Name"]][0]
     prof_us = float(row["AverageNs"]) / 1e3
     assert abs(prof_us / d["roofline"]["avg_launch_us"] - 1.0) < 0.10, (prof_us, d["roofline"]["avg_launch_us"])
+
+
+def test_bench_flags_parse():
+    """The command lines DESIGN/README quote, and the driver's own, are accepted by bench.py's parser."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = sys.argv
+    try:
+        for argv in (["--gpus", "8", "--steps", "20", "--warmup", "5"],
+                     ["--mode", "graph"],
+                     ["--fanout", "10,10,10", "--e2e-model", "gat", "--e2e-hidden", "32"],
+                     ["--no-e2e-multi", "--e2e-timeout", "30"],
+                     ["--serial-rounds", "--no-cpu-baseline", "--no-kernel-timing", "--e2e-steps", "0"]):
+            sys.argv = ["bench.py"] + argv
+            a = mod.parse()
+            assert a.steps > 0 and a.mode in ("strict", "graph")
+    finally:
+        sys.argv = old
+
+
+def test_split_k_linear_on_cpu():
+    """splitgnn._SplitKLinear is plain torch: its slab-wise weight gradient equals F.linear's on the CPU too."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "occ-gnn_amd"))
+    from cslicer import splitgnn
+    torch.manual_seed(0)
+    m = splitgnn.ROW_PAD
+    x = torch.rand((m, 24), dtype=torch.float64, requires_grad=True)
+    w = torch.rand((8, 24), dtype=torch.float64, requires_grad=True)
+    b = torch.rand((8,), dtype=torch.float64, requires_grad=True)
+    gy = torch.rand((m, 8), dtype=torch.float64)
+    g0 = torch.autograd.grad(torch.nn.functional.linear(x, w, b), (x, w, b), gy)
+    g1 = torch.autograd.grad(splitgnn._SplitKLinear.apply(x, w, b), (x, w, b), gy)
+    for a_, b_ in zip(g0, g1):
+        assert torch.allclose(a_, b_, rtol=1e-12, atol=1e-12)
+    (gx, gw) = torch.autograd.grad(splitgnn._SplitKLinear.apply(x, w, None), (x, w), gy)
+    assert torch.allclose(gw, g0[1], rtol=1e-12, atol=1e-12)
