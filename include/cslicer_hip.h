@@ -192,9 +192,10 @@ int64_t csl_copy_list(csl_engine* e, int32_t slot, int32_t stream, int32_t layer
 int csl_fetch_sample(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta,
                      const int64_t** host_ptr, int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS]);
 
-/* Same batch of copies without the widening pass: *host_ptr is the pinned int32 staging
- * buffer itself (valid until the next fetch); the caller widens while filling its own
- * `long` vectors. */
+/* Same without the widening pass: *host_ptr is the pinned int32 staging buffer itself.  Two staging
+ * buffers alternate, so the pointer stays valid until the SECOND next fetch: a caller may widen sample k
+ * into its own `long` vectors on one thread while another thread already fetches sample k+1.  (The sample
+ * leaves the GPU as one packed D2H copy: a small kernel gathers its ~30 list segments first.) */
 int csl_fetch_sample32(csl_engine* e, int32_t slot, int32_t stream, csl_sample_meta* meta,
                        const int32_t** host_ptr, int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS]);
 

@@ -1392,6 +1392,20 @@ __global__ void k_pack_off32(const long long* indptr, uint32_t* off32, size_t n1
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n1; i += stride) off32[i] = (uint32_t)indptr[i];
 }
+// csl_fetch_sample*: gathers one sample's lists (a segment per layer and list kind, spread over the arenas)
+// into ONE contiguous device buffer, so that the sample leaves the GPU in a single D2H copy instead of ~30
+struct FetchSegs {
+  const int* src[CSL_MAX_LAYERS * CSL_NUM_LISTS];
+  uint32_t dst[CSL_MAX_LAYERS * CSL_NUM_LISTS];
+  uint32_t n[CSL_MAX_LAYERS * CSL_NUM_LISTS];
+  int count;
+};
+__global__ __launch_bounds__(256) void k_pack_sample(FetchSegs f, int* out) {
+  const int* src = f.src[blockIdx.y];
+  int* dst = out + f.dst[blockIdx.y];
+  const uint32_t n = f.n[blockIdx.y];
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+}
 __global__ void k_pack_indices(const long long* src, uint32_t* dst, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1512,7 +1526,10 @@ struct csl_engine {
   BatchDesc* desc_dev = nullptr;   // [slots][S]
   BatchDesc* desc_host = nullptr;  // pinned, [slots][S]
   // pinned staging for csl_fetch_sample
-  int* fetch_stage = nullptr;       // pinned int32 staging
+  int* fetch_stage = nullptr;       // pinned int32 staging of the sample handed out last
+  int* fetch_stage2[2] = {nullptr, nullptr};  // two buffers: the caller may still read one while the next fills
+  int* fetch_pack = nullptr;        // device: the sample's lists back to back (k_pack_sample)
+  int fetch_flip = 0;
   long long* fetch_host = nullptr;  // widened copy handed to the caller
   size_t fetch_cap = 0;
   hipStream_t copy_stream = nullptr;
@@ -1908,7 +1925,9 @@ void csl_destroy(csl_engine* e) {
   for (int l = 0; l < CSL_MAX_LAYERS; l++)
     if (e->arena[l]) hipFree(e->arena[l]);
   if (e->desc_host) hipHostFree(e->desc_host);
-  if (e->fetch_stage) hipHostFree(e->fetch_stage);
+  for (int k = 0; k < 2; k++)
+    if (e->fetch_stage2[k]) hipHostFree(e->fetch_stage2[k]);
+  if (e->fetch_pack) hipFree(e->fetch_pack);
   free(e->fetch_host);
   if (e->copy_stream) hipStreamDestroy(e->copy_stream);
   if (e->rng_event) hipEventDestroy(e->rng_event);
@@ -2301,26 +2320,43 @@ static int fetch_stage(csl_engine* e, int32_t slot, int32_t stream, csl_sample_m
   const csl_sample_meta& sm = e->meta_host[(size_t)slot * e->S + stream];
   *meta = sm;
   if (sm.error) return fail(CSL_E_DEVICE, "device flagged error bits 0x%x in slot %d stream %d", sm.error, slot, stream);
-  if (!e->fetch_stage) {
+  if (!e->fetch_pack) {
     size_t cap = 0;
     for (int l = 0; l < e->L; l++) cap += e->arena_stride[l];
-    HIPCHECK(hipHostMalloc((void**)&e->fetch_stage, cap * sizeof(int), hipHostMallocDefault));
+    for (int k = 0; k < 2; k++) HIPCHECK(hipHostMalloc((void**)&e->fetch_stage2[k], cap * sizeof(int), hipHostMallocDefault));
+    HIPCHECK(hipMalloc((void**)&e->fetch_pack, cap * sizeof(int)));
     e->fetch_host = (long long*)malloc(cap * sizeof(long long));
     if (!e->fetch_host) return fail(CSL_E_NOMEM, "host allocation failed");
     e->fetch_cap = cap;
     HIPCHECK(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
   }
+  e->fetch_flip ^= 1;
+  e->fetch_stage = e->fetch_stage2[e->fetch_flip];
+  FetchSegs f;
+  f.count = 0;
   size_t o = 0;
+  uint32_t longest = 0;
   for (int l = 0; l < e->L; l++) {
     const int* base = e->arena[l] + ((size_t)slot * e->S + stream) * e->arena_stride[l];
     for (int k = 0; k < CSL_NUM_LISTS; k++) {
       const size_t n = sm.layer[l].off[k][e->P];
       seg[l][k] = (int64_t)o;
-      if (n)
-        HIPCHECK(hipMemcpyAsync(e->fetch_stage + o, base + e->list_base[l][k], n * sizeof(int),
-                                hipMemcpyDeviceToHost, e->copy_stream));
+      if (n) {
+        f.src[f.count] = base + e->list_base[l][k];
+        f.dst[f.count] = (uint32_t)o;
+        f.n[f.count] = (uint32_t)n;
+        f.count++;
+        if (n > longest) longest = (uint32_t)n;
+      }
       o += n;
     }
+  }
+  if (o) {
+    unsigned gx = (longest + 256 * 8 - 1) / (256 * 8);
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k_pack_sample, dim3(gx, (unsigned)f.count), dim3(256), 0, e->copy_stream, f, e->fetch_pack);
+    HIPCHECK(hipMemcpyAsync(e->fetch_stage, e->fetch_pack, o * sizeof(int), hipMemcpyDeviceToHost, e->copy_stream));
   }
   HIPCHECK(hipStreamSynchronize(e->copy_stream));
   *total = o;

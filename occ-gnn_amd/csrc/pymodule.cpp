@@ -23,6 +23,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <fstream>
+#include <functional>
 #include <mutex>
 #include <queue>
 #include <stdexcept>
@@ -111,6 +112,68 @@ struct L0Dataset {
     f.read(reinterpret_cast<char*>(dst.data()), (std::streamsize)(dst.size() * sizeof(long)));
     if ((size_t)f.gcount() != dst.size() * sizeof(long)) throw std::runtime_error("cslicer: short read of " + path);
   }
+};
+
+// A few helper threads for the int32 -> long deep copy of one sample (12 bipartites, the deepest layer's
+// four hold ~80 % of the ids): the caller takes part, tasks are claimed with an atomic counter.
+class MiniPool {
+ public:
+  explicit MiniPool(int n) {
+    for (int i = 0; i < n; i++) th_.emplace_back([this] { worker(); });
+  }
+  ~MiniPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  void run(int n_tasks, const std::function<void(int)>& fn) {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn;
+      n_tasks_ = n_tasks;
+      pending_ = n_tasks;
+      gen_++;
+      next_.store(0);  // last: a helper that sees the new counter sees the new task set
+    }
+    cv_.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(m_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+  }
+
+ private:
+  void work() {
+    for (;;) {
+      const int t = next_.fetch_add(1);
+      if (t >= n_tasks_) return;
+      (*fn_)(t);
+      std::lock_guard<std::mutex> lk(m_);
+      if (--pending_ == 0) done_cv_.notify_all();
+    }
+  }
+  void worker() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+        if (stop_) return;
+        seen = gen_;
+      }
+      work();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int n_tasks_ = 0, pending_ = 0;
+  std::atomic<int> next_{1 << 30};
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
 };
 
 // ---- ConQueue<PySample*>: util/conqueue.h:10-63, plus a close() so that the
@@ -263,28 +326,45 @@ class CSlicer {
   }
 
  private:
-  PySample* fetch(int slot, int stream) {
+  // One sample on its way out: the packed int32 lists in the engine's pinned staging (two buffers alternate,
+  // so the converter may still read sample k while the producer fetches sample k+1) + where each list sits.
+  struct Staged {
     csl_sample_meta m;
-    const int32_t* host = nullptr;  // pinned int32 staging: widened while the vectors are filled
+    const int32_t* host = nullptr;
     int64_t seg[CSL_MAX_LAYERS][CSL_NUM_LISTS];
-    check(csl_fetch_sample32(eng_, slot, stream, &m, &host, seg), "csl_fetch_sample32");
+  };
+
+  void fetch(int slot, int stream, Staged* st) {
+    check(csl_fetch_sample32(eng_, slot, stream, &st->m, &st->host, st->seg), "csl_fetch_sample32");
+  }
+
+  // PySample(Sample*) (pybipartite.cpp:54-66): the deep copy into `long` vectors, int32 -> long on the way
+  PySample* convert(const Staged& st) {
+    const csl_sample_meta& m = st.m;
     PySample* s = empty_sample(n_layers_, n_parts_);
     auto take = [&](int l, int kind, int g, std::vector<long>& dst) {
       const long lo = (long)m.layer[l].off[kind][g], hi = (long)m.layer[l].off[kind][g + 1];
-      const int32_t* src = host + seg[l][kind] + lo;
+      const int32_t* src = st.host + st.seg[l][kind] + lo;
       dst.assign(src, src + (hi - lo));  // int32 -> long
     };
+    const std::function<void(int)> one = [&](int t) {
+      const int l = t / n_parts_, g = t % n_parts_;
+      PyBipartite* b = (*s->layers[l])[g];
+      take(l, CSL_IN_NODES, g, b->in_nodes);
+      take(l, CSL_OUT_NODES, g, b->out_nodes);
+      take(l, CSL_OWNED_OUT_NODES, g, b->owned_out_nodes);
+      take(l, CSL_SELF_IDS_IN, g, b->self_ids_in);
+      take(l, CSL_SELF_IDS_OUT, g, b->self_ids_out);
+      take(l, CSL_TO_IDS, g, b->to_ids[g]);      // own index only, slicer.cpp:41
+      take(l, CSL_FROM_IDS, g, b->from_ids[g]);  // slicer.cpp:42
+      b->indptr.assign(b->out_nodes.size(), 1);  // bipartite.h:55-66: one `1` per push, CSR never built
+    };
+    // deepest layer first: its bipartites are the big tasks
+    const std::function<void(int)> rev = [&](int t) { one(n_layers_ * n_parts_ - 1 - t); };
+    pool_.run(n_layers_ * n_parts_, rev);
     for (int l = 0; l < n_layers_; l++) {
       for (int g = 0; g < n_parts_; g++) {
         PyBipartite* b = (*s->layers[l])[g];
-        take(l, CSL_IN_NODES, g, b->in_nodes);
-        take(l, CSL_OUT_NODES, g, b->out_nodes);
-        take(l, CSL_OWNED_OUT_NODES, g, b->owned_out_nodes);
-        take(l, CSL_SELF_IDS_IN, g, b->self_ids_in);
-        take(l, CSL_SELF_IDS_OUT, g, b->self_ids_out);
-        take(l, CSL_TO_IDS, g, b->to_ids[g]);      // own index only, slicer.cpp:41
-        take(l, CSL_FROM_IDS, g, b->from_ids[g]);  // slicer.cpp:42
-        b->indptr.assign(b->out_nodes.size(), 1);  // bipartite.h:55-66: one `1` per push, CSR never built
         if (l == 0) s->in_nodes += (long)b->in_nodes.size();
         if (g == 2) s->out_nodes += (long)b->out_nodes.size();
       }
@@ -292,39 +372,95 @@ class CSlicer {
     return s;
   }
 
+  // Hand-over producer -> converter, one sample deep (the staging has two buffers): D2H of sample k+1
+  // overlaps the widening of sample k.  Returns false when the consumer has gone away.
+  bool hand_over(const Staged& st) {
+    std::unique_lock<std::mutex> lk(cv_m_);
+    cv_.wait(lk, [&] { return !have_staged_ || conv_stop_; });
+    if (conv_stop_) return false;
+    staged_ = st;
+    have_staged_ = true;
+    cv_.notify_all();
+    return true;
+  }
+
+  void converter() {
+    for (;;) {
+      Staged st;
+      {
+        std::unique_lock<std::mutex> lk(cv_m_);
+        cv_.wait(lk, [&] { return have_staged_ || conv_done_ || conv_stop_; });
+        if (conv_stop_ || (!have_staged_ && conv_done_)) return;
+        st = staged_;
+      }
+      PySample* smp = convert(st);   // reads st.host while the producer may already fetch the next sample
+      {
+        std::lock_guard<std::mutex> lk(cv_m_);
+        have_staged_ = false;        // the staging buffer two fetches back is free again
+        cv_.notify_all();
+      }
+      if (!ready_.push(smp)) {
+        delete smp;
+        std::lock_guard<std::mutex> lk(cv_m_);
+        conv_stop_ = true;
+        cv_.notify_all();
+        return;
+      }
+    }
+  }
+
   // WorkerPool::run (WorkerPool.cpp:37-60)
   void run() {
+    std::thread conv(&CSlicer::converter, this);
     try {
       std::vector<long> nodes(num_nodes_);
       for (long i = 0; i < num_nodes_; i++) nodes[i] = i;  // WorkerPool.cpp:12-16
       const long per_epoch = (num_nodes_ - 1) / batch_ + 1;
       const long rounds = (per_epoch + workers_ - 1) / workers_;
-      for (int epoch = 0; epoch < epochs_ && !stop_; epoch++) {
+      bool alive = true;
+      for (int epoch = 0; epoch < epochs_ && !stop_ && alive; epoch++) {
         if (shuffle_) std::random_shuffle(nodes.begin(), nodes.end());  // WorkerPool.cpp:40
         check(csl_set_nodes(eng_, reinterpret_cast<const int64_t*>(nodes.data()), num_nodes_), "csl_set_nodes");
         int inflight_slot = -1, inflight_n = 0;
-        for (long r = 0; r <= rounds && !stop_; r++) {
+        for (long r = 0; r <= rounds && !stop_ && alive; r++) {
           int slot = (int)(r & 1), nb = 0;
           if (r < rounds) {
             nb = (int)std::min<long>(workers_, per_epoch - r * workers_);
             check(csl_submit_round(eng_, r * workers_, batch_, nb, slot), "csl_submit_round");
           }
           // hand out the previous round while the GPU works on this one
-          for (int s = 0; s < inflight_n && !stop_; s++) {
-            PySample* smp = fetch(inflight_slot, s);
-            if (!ready_.push(smp)) {
-              delete smp;
-              return;
-            }
+          for (int s = 0; s < inflight_n && !stop_ && alive; s++) {
+            Staged st;
+            fetch(inflight_slot, s, &st);
+            alive = hand_over(st);
           }
           inflight_slot = slot;
           inflight_n = nb;
         }
       }
     } catch (const std::exception& ex) {
+      {
+        std::lock_guard<std::mutex> lk(cv_m_);
+        conv_stop_ = true;
+        cv_.notify_all();
+      }
+      conv.join();
       ready_.close(ex.what());
+      return;
     }
+    {
+      std::lock_guard<std::mutex> lk(cv_m_);
+      conv_done_ = true;
+      cv_.notify_all();
+    }
+    conv.join();
   }
+
+  MiniPool pool_{3};
+  std::mutex cv_m_;
+  std::condition_variable cv_;
+  Staged staged_;
+  bool have_staged_ = false, conv_done_ = false, conv_stop_ = false;
 };
 
 py::list testlist(py::list l) {  // pyfrontend.cpp:94-109
