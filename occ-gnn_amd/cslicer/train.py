@@ -139,3 +139,87 @@ def synthetic_node_data(num_nodes, feat_dim, n_classes, seed=0):
     feats = rng.random((num_nodes, feat_dim), dtype=np.float32)
     labels = rng.integers(0, n_classes, size=num_nodes).astype(np.int64)
     return feats, labels
+
+
+def main(argv=None):
+    """Command line with the argument names of the reference's python/train.py:109-131 (same spelling, same
+    defaults where they apply); one process per GPU under torchrun, or a single process.
+
+        python -m cslicer.train --graph synthetic --model-name gcn --fan-out 5,10,15 --batch-size 1024
+        python -m torch.distributed.run --nproc-per-node 4 --master-addr 127.0.0.1 -m cslicer.train --graph <L0 dir>
+
+    --fan-out follows the reference (DGL) convention, input side first (python/train.py:128,
+    batch_slice_multi_gpu.py:202): the LAST number is the hop from the seeds.  --graph: an L0 directory
+    (cslicer.l0), a preset name (arxiv-like, products-like, papers-like) or `synthetic`.
+    Accepted and ignored (no counterpart here): --cache-per (features are resident in HBM), --num-workers,
+    --dropout, --debug, --log-every, --eval-every."""
+    import argparse
+    import os
+    ap = argparse.ArgumentParser("split-parallel training on MI355X")
+    ap.add_argument("--graph", type=str, default="synthetic")
+    ap.add_argument("--log-every", type=int, default=20)
+    ap.add_argument("--eval-every", type=int, default=5)
+    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--num-workers", type=int, default=0)
+    ap.add_argument("--debug", type=bool, default=False)
+    ap.add_argument("--cache-per", type=float)
+    ap.add_argument("--model-name", default="gcn", help="gcn|gat")
+    ap.add_argument("--num-epochs", type=int, default=2)
+    ap.add_argument("--num-hidden", type=int, default=256)
+    ap.add_argument("--num-layers", type=int, default=3)
+    ap.add_argument("--num-heads", type=int, default=8)
+    ap.add_argument("--fan-out", type=str, default="10,10,25")
+    ap.add_argument("--batch-size", type=int, default=1032)
+    ap.add_argument("--dropout", type=float, default=0)
+    ap.add_argument("--max-steps", type=int, default=0, help="(extra) stop an epoch after this many minibatches")
+    a = ap.parse_args(argv)
+    from . import l0
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend=os.environ.get("CSLICER_DIST_BACKEND", "nccl"))
+    if a.graph == "synthetic":
+        indptr, indices = l0.synth_graph(200_000, 20.0, seed=0)
+        feats, labels = synthetic_node_data(indptr.shape[0] - 1, 128, 40, seed=0)
+        n_classes = 40
+    elif a.graph in l0.PRESETS:
+        n, d, fdim, n_classes = l0.PRESETS[a.graph]
+        indptr, indices = l0.synth_graph(n, d, seed=0)
+        feats, labels = synthetic_node_data(n, fdim, n_classes, seed=0)
+    else:
+        indptr, indices, meta = l0.read_l0(a.graph, mmap=False)
+        n = meta["num_nodes"]
+        feats = np.fromfile(os.path.join(a.graph, "features.bin"), dtype=np.float32).reshape(n, meta["feature_dim"])
+        labels = np.fromfile(os.path.join(a.graph, "labels.bin"), dtype=np.int32).astype(np.int64)
+        n_classes = meta["num_classes"]
+    fan = tuple(int(x) for x in a.fan_out.split(","))[::-1]          # engine order: layer 0 = hop from the seeds
+    if len(fan) != a.num_layers:
+        fan = fan[:a.num_layers] if len(fan) > a.num_layers else fan
+    kind = "gat" if a.model_name == "gat" else "sage"
+    hidden = a.num_hidden // a.num_heads if kind == "gat" else a.num_hidden
+    tr = Trainer(indptr, indices, feats, labels, n_classes, rank=rank, world=world, fanouts=fan, batch=a.batch_size,
+                 streams=8, hidden=max(4, hidden // 4 * 4), lr=a.lr, device=local, dist=dist, model=kind, heads=a.num_heads)
+    n = indptr.shape[0] - 1
+    for epoch in range(a.num_epochs):
+        tr.set_nodes(np.random.default_rng(epoch).permutation(n))
+        steps = tr.n_batches if a.max_steps <= 0 else min(a.max_steps, tr.n_batches)
+        t0 = time.time()
+        losses = tr.run(steps)
+        if rank == 0:
+            print("epoch %d: %d minibatches in %.2f s, loss %.4f -> %.4f" % (epoch, steps, time.time() - t0, losses[0], losses[-1]))
+    if rank == 0:
+        print(tr.report())
+    tr.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    import sys
+    main(sys.argv[1:])

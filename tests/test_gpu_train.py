@@ -134,3 +134,16 @@ def test_batch_slice_script_prints_exp5_keys(capsys):
                 r"data transfer:(\d+\.\d+)", r"graph splitting time:(\d+\.\d+)"):
         m = re.findall(pat, out)
         assert len(m) == 1 and float(m[0]) >= 0.0, (pat, out)
+
+
+@pytest.mark.parametrize("model", ["gcn", "gat"])
+def test_train_cli_prints_reference_keys(capsys, model):
+    """`python -m cslicer.train` with the reference's argument names (python/train.py:109-131) runs a few
+    minibatches and prints the keys experiments/exp6/occ.py:21-23 parses."""
+    from cslicer import train
+    train.main(["--graph", "synthetic", "--model-name", model, "--fan-out", "5,10", "--num-layers", "2",
+                "--num-hidden", "32", "--num-heads", "2", "--batch-size", "256", "--num-epochs", "1", "--max-steps", "4",
+                "--cache-per", "0.25", "--num-workers", "0"])
+    out = capsys.readouterr().out
+    for key in ("avg forward time", "batch slice time", "cache refresh time"):
+        assert key in out
