@@ -112,6 +112,8 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
     return out
 
 
+import os as _os
+_NO_LOCAL_FUSE = bool(_os.environ.get("CSLICER_NO_LOCAL_FUSE"))   # A/B switch for the single-part fused layer
 ROW_PAD = 4096   # GEMM row counts are rounded up to a multiple of this (see DistSageConv.finish)
 SPLIT_K = 32     # the weight-gradient GEMM reduces over the rows in this many independent slabs
 
@@ -146,7 +148,12 @@ class _SageFinish(torch.autograd.Function):
     bound by host-side op dispatch, not by the GPU, so fewer nodes is what counts."""
 
     @staticmethod
-    def forward(ctx, x, agg, weight, bias, self_ids_in, owned, deg, relu):
+    def forward(ctx, x, agg, weight, bias, self_ids_in, owned, deg, relu, indptr=None, indices=None, n_out=0):
+        # agg is None: the whole layer of a single part (no boundary exchange): the CSR aggregation happens
+        # in here too, and the backward sends the neighbour gradient straight through the CSR
+        ctx.local = agg is None
+        if ctx.local:
+            agg = aggr.spmm_sum(indptr, indices, x, n_out)
         m, fin = owned.numel(), x.shape[1]
         mp = (m + ROW_PAD - 1) // ROW_PAD * ROW_PAD if m >= ROW_PAD else m
         cat = torch.empty((mp, 2 * fin), dtype=torch.float32, device=x.device)
@@ -158,12 +165,13 @@ class _SageFinish(torch.autograd.Function):
         if relu:
             y.relu_()
         ctx.relu, ctx.m, ctx.n_x, ctx.n_agg = relu, m, x.shape[0], agg.shape[0]
-        ctx.save_for_backward(cat, weight, self_ids_in, owned, deg, y if relu else None)
+        ctx.save_for_backward(cat, weight, self_ids_in, owned, deg, y if relu else None,
+                              indptr if ctx.local else None, indices if ctx.local else None)
         return y[:m]
 
     @staticmethod
     def backward(ctx, gy):
-        cat, weight, self_ids_in, owned, deg, y = ctx.saved_tensors
+        cat, weight, self_ids_in, owned, deg, y, indptr, indices = ctx.saved_tensors
         m, mp, fin = ctx.m, cat.shape[0], cat.shape[1] // 2
         if ctx.relu:
             gy = gy * (y[:m] > 0)
@@ -179,15 +187,18 @@ class _SageFinish(torch.autograd.Function):
             gw = gyp.t() @ cat
         gb = gyp.sum(0)
         gx = gagg = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not ctx.local):
             gcat = gyp @ weight
             if ctx.needs_input_grad[0]:
                 gx = torch.zeros((ctx.n_x, fin), dtype=torch.float32, device=gy.device)
                 aggr.scatter_add_rows_(gx, self_ids_in, gcat[:m, :fin])
-            if ctx.needs_input_grad[1]:
+                if ctx.local:  # neighbour gradient of the owned rows, through the CSR, into the same buffer
+                    aggr.spmm_sum_bwd(indptr, indices, aggr.div_rows_(gcat[:m, fin:], deg), ctx.n_x, rows=owned,
+                                      compact=True, out=gx)
+            if ctx.needs_input_grad[1] and not ctx.local:
                 gagg = torch.zeros((ctx.n_agg, fin), dtype=torch.float32, device=gy.device)
                 aggr.scatter_add_rows_(gagg, owned, aggr.div_rows_(gcat[:m, fin:], deg))
-        return gx, gagg, gw, gb, None, None, None, None
+        return gx, gagg, gw, gb, None, None, None, None, None, None, None
 
 
 class DistSageConv(nn.Module):
@@ -219,6 +230,11 @@ class DistSageConv(nn.Module):
         """finish (+ ReLU) as one autograd node (`_SageFinish`); same numbers as finish + torch.relu."""
         return _SageFinish.apply(x, agg, self.fc.weight, self.fc.bias, sl.self_ids_in, sl.owned_out_nodes,
                                  sl.owned_degree, relu)
+
+    def layer_local(self, sl, x, relu):
+        """A whole layer of a single part (n_parts == 1: nothing to exchange) as one autograd node."""
+        return _SageFinish.apply(x, None, self.fc.weight, self.fc.bias, sl.self_ids_in, sl.owned_out_nodes,
+                                 sl.owned_degree, relu, sl.indptr, sl.indices, sl.n_out)
 
     def finish(self, sl, agg, x):
         """slice_owned_nodes + mean + self_gather + concat + Linear."""
@@ -256,6 +272,9 @@ class DistSAGEModel(nn.Module):
         x = {g: feats[g] for g in parts}
         for k, conv in enumerate(self.convs):
             sl = slices[L - 1 - k]
+            if len(parts) == 1 and sl[parts[0]].n_parts == 1 and not _NO_LOCAL_FUSE:
+                x = {parts[0]: conv.layer_local(sl[parts[0]], x[parts[0]], k + 1 < len(self.convs))}
+                continue
             agg = {g: conv.local(sl[g], x[g]) for g in parts}
             send = {g: conv.boundary(sl[g], agg[g]) for g in parts}
             for g in parts:
