@@ -37,7 +37,14 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None and t.numel() else C.c_void_p(0)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream.  The raw getter avoids building a torch.cuda.Stream object per
+    kernel call (a training step makes ~25 of them: 0.13 ms of host time per step in the profile)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
