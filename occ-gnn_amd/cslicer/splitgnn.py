@@ -174,12 +174,8 @@ class _SageFinish(torch.autograd.Function):
         cat, weight, self_ids_in, owned, deg, y, indptr, indices = ctx.saved_tensors
         m, mp, fin = ctx.m, cat.shape[0], cat.shape[1] // 2
         if ctx.relu:
-            gy = gy * (y[:m] > 0)
-        if mp != m:
-            gyp = torch.zeros((mp, gy.shape[1]), dtype=torch.float32, device=gy.device)
-            gyp[:m] = gy
-        else:
-            gyp = gy.contiguous()
+            gy = torch.ops.aten.threshold_backward(gy, y[:m], 0.0)   # ReLU backward, one kernel
+        gyp = torch.nn.functional.pad(gy, (0, 0, 0, mp - m)) if mp != m else gy.contiguous()
         if mp >= ROW_PAD and mp % SPLIT_K == 0:
             gw = torch.bmm(gyp.view(SPLIT_K, mp // SPLIT_K, gyp.shape[1]).transpose(1, 2),
                            cat.view(SPLIT_K, mp // SPLIT_K, cat.shape[1])).sum(0)
