@@ -24,7 +24,7 @@ from . import _abi, aggr, splitgnn
 class Trainer(object):
     def __init__(self, indptr, indices, features, labels, n_classes, rank=0, world=1, fanouts=(15, 10, 5),
                  batch=1024, streams=8, hidden=256, lr=1e-3, device=0, dist=None, seed=0, overlap=False,
-                 model="sage", heads=8):
+                 model="sage", heads=8, rank_path=None):
         """features: float32 [N, F] (host, the rank keeps only the rows it owns); labels int64 [N]."""
         self.rank, self.world, self.dist = rank, world, dist
         self.P = world
@@ -47,7 +47,10 @@ class Trainer(object):
         else:
             raise ValueError("model must be 'sage' or 'gat'")
         self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
-        self.comm = splitgnn.DistComm(device=self.dev) if world > 1 else None
+        # rank_path=True forces the one-process-per-part code (collectives included) even for a single part:
+        # a way to run the RCCL calls on a one-GPU box
+        self.rank_path = (world > 1) if rank_path is None else bool(rank_path)
+        self.comm = splitgnn.DistComm(device=self.dev) if self.rank_path else None
         self.overlap = overlap
         self.t_forward = self.t_slice = 0.0
         self.steps_done = 0
@@ -66,7 +69,7 @@ class Trainer(object):
         rows = deep.in_nodes if self.P == 1 else torch.div(deep.in_nodes, self.P, rounding_mode="floor")
         x = aggr.gather_rows(self.feat, rows)
         t1 = time.perf_counter()
-        if self.world > 1:
+        if self.rank_path:
             if self.kind == "gat":
                 logits = self.model.forward_rank(slices, x, self.rank, self.comm)
             else:
@@ -82,7 +85,7 @@ class Trainer(object):
         self.t_forward += time.perf_counter() - t1
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
-        if self.world > 1:
+        if self.rank_path:
             # (a rank whose share of the minibatch produced no gradient for a parameter still takes part)
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                               for p in self.model.parameters()])

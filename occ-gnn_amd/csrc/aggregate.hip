@@ -314,8 +314,8 @@ extern "C" {
 
 int csl_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
                      const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, void* stream) {
+  if (n_rows == 0) return CSL_OK;  // nothing to do: empty lists come with null pointers
   if (n_rows < 0 || H < 1 || !indptr || !out || ldx < H || ldo < H) return CSL_E_INVALID;
-  if (n_rows == 0) return CSL_OK;
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(x, ldx, out, ldo, H);
   DISPATCH_G(G, k_spmm_sum, n_rows, indptr, indices, rows,
@@ -326,8 +326,8 @@ int csl_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const int32_
 int csl_spmm_sum_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
                          const float* grad_out, int64_t ldg, int32_t compact, float* grad_x, int64_t ldx, int32_t H,
                          void* stream) {
-  if (n_rows < 0 || H < 1 || !indptr || !grad_out || !grad_x) return CSL_E_INVALID;
   if (n_rows == 0) return CSL_OK;
+  if (n_rows < 0 || H < 1 || !indptr || !grad_out || !grad_x) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_spmm_sum_bwd, dim3((unsigned)((n_rows + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st,
                      indptr, indices, rows, (long long)n_rows,
@@ -337,8 +337,8 @@ int csl_spmm_sum_bwd_f32(const int32_t* indptr, const int32_t* indices, const in
 
 int csl_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, int64_t n, float* dst, int64_t ldd,
                         int32_t H, void* stream) {
-  if (n < 0 || H < 1 || !idx || !dst) return CSL_E_INVALID;
   if (n == 0) return CSL_OK;
+  if (n < 0 || H < 1 || !idx || !dst) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(src, lds, dst, ldd, H);
   DISPATCH_G(G, k_gather_rows, n, src, (long long)lds, idx, (long long)n, dst, (long long)ldd, (int)H, v);
@@ -347,8 +347,8 @@ int csl_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, int64
 
 int csl_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t n, const float* src, int64_t lds,
                              int32_t H, void* stream) {
-  if (n < 0 || H < 1 || !idx || !dst || !src) return CSL_E_INVALID;
   if (n == 0) return CSL_OK;
+  if (n < 0 || H < 1 || !idx || !dst || !src) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(src, lds, dst, ldd, H);
   DISPATCH_G(G, k_scatter_add_rows, n, dst, (long long)ldd, idx, (long long)n, src, (long long)lds,
@@ -357,8 +357,8 @@ int csl_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_
 }
 
 int csl_div_rows_f32(float* x, int64_t ldx, const int32_t* deg, int64_t n, int32_t H, void* stream) {
-  if (n < 0 || H < 1 || !x || !deg) return CSL_E_INVALID;
   if (n == 0) return CSL_OK;
+  if (n < 0 || H < 1 || !x || !deg) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(x, ldx, x, ldx, H);
   DISPATCH_G(G, k_div_rows, n, x, (long long)ldx, deg, (long long)n, (int)H, v);
@@ -373,9 +373,9 @@ static int gat_args_ok(const void* a, const void* b, const void* c, int32_t H, i
 int csl_gat_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, const float* el, const float* er,
                     const float* z, int32_t H, int32_t D, float slope, float* m_out, float* s_out, float* n_out,
                     void* stream) {
+  if (n_rows == 0) return CSL_OK;
   if (n_rows < 0 || !indptr || !er || !m_out || !s_out || !n_out || !gat_args_ok(z, n_out, n_out, H, D))
     return CSL_E_INVALID;
-  if (n_rows == 0) return CSL_OK;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gat_fwd, dim3((unsigned)((n_rows + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, indptr,
                      indices, (long long)n_rows, el, er, z, (int)H, (int)D, slope, m_out, s_out, n_out);
@@ -385,9 +385,9 @@ int csl_gat_fwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_row
 int csl_gat_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_rows, const float* el, const float* er,
                     const float* z, int32_t H, int32_t D, float slope, const float* m_in, const float* g_s,
                     const float* g_n, float* g_el, float* g_er, float* g_z, void* stream) {
+  if (n_rows == 0) return CSL_OK;
   if (n_rows < 0 || !indptr || !er || !m_in || !g_s || !g_n || !g_er || !gat_args_ok(z, g_n, g_z, H, D))
     return CSL_E_INVALID;
-  if (n_rows == 0) return CSL_OK;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gat_bwd, dim3((unsigned)((n_rows + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, indptr,
                      indices, (long long)n_rows, el, er, z, (int)H, (int)D, slope, m_in, g_s, g_n, g_el, g_er, g_z);

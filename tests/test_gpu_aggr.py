@@ -238,3 +238,22 @@ def test_fused_finish_matches_the_op_chain(m, fin, relu):
     for nme, a_, b_ in zip(names, outs[0], outs[1]):
         tol = 1e-5 if nme == "y" else 1e-4
         assert torch.allclose(a_, b_, rtol=tol, atol=tol * max(1.0, float(a_.abs().max()))), (nme, float((a_ - b_).abs().max()))
+
+
+def test_empty_lists_are_no_ops(mods):
+    """A part without boundary rows hands empty index lists (null device pointers) to the kernels' C entry
+    points: they return success and touch nothing (found with the RCCL world-of-one test)."""
+    _, aggr, _ = mods
+    x = torch.rand((10, 8), device="cuda")
+    empty = torch.zeros(0, dtype=torch.int32, device="cuda")
+    assert aggr.gather_rows(x, empty).shape == (0, 8)
+    y = x.clone()
+    aggr.scatter_add_rows_(y, empty, torch.zeros((0, 8), device="cuda"))
+    assert torch.equal(x, y)
+    ip = torch.zeros(11, dtype=torch.int32, device="cuda")
+    out = torch.full((10, 8), 7.0, device="cuda")
+    aggr.spmm_sum(ip, empty, x, 10, rows=empty, out=out)
+    assert bool((out == 7.0).all())
+    g = aggr.spmm_sum_bwd(ip, empty, torch.zeros((0, 8), device="cuda"), 10, rows=empty, compact=True)
+    assert g.shape == (10, 8) and float(g.abs().sum()) == 0.0
+    aggr.div_rows_(torch.zeros((0, 8), device="cuda"), empty)

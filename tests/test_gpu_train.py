@@ -54,6 +54,14 @@ def _rank_main(rank, world, port, q, overlap=False, kind="sage"):
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _rank_body(rank, world, q, overlap, kind, dist)
+    except Exception as ex:      # the parent must hear about it instead of waiting for the queue
+        q.put((rank, "error: " + repr(ex), None))
+        raise
+
+
+def _rank_body(rank, world, q, overlap, kind, dist):
     from cslicer.train import Trainer
     from test_gpu_train import _task
     indptr, indices, feats, labels, perm = _task()
@@ -82,7 +90,9 @@ def test_two_ranks_match_single_process_two_parts(overlap, kind):
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, overlap, kind)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda x: x[0])
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
+    for r_ in res:
+        assert not isinstance(r_[1], str), r_[1]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -147,3 +157,57 @@ def test_train_cli_prints_reference_keys(capsys, model):
     out = capsys.readouterr().out
     for key in ("avg forward time", "batch slice time", "cache refresh time"):
         assert key in out
+
+
+def _nccl_single_rank(port, q, kind):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "occ-gnn_amd"))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from cslicer.train import Trainer
+    from test_gpu_train import _task
+    indptr, indices, feats, labels, perm = _task()
+    out = []
+    try:
+        _nccl_runs(Trainer, dist, indptr, indices, feats, labels, perm, kind, out)
+    except Exception as ex:      # the parent must hear about it instead of waiting for the queue
+        q.put(("error", repr(ex), None))
+        raise
+    q.put(out)
+    dist.destroy_process_group()
+
+
+def _nccl_runs(Trainer, dist, indptr, indices, feats, labels, perm, kind, out):
+    for rank_path, overlap in ((False, False), (True, False), (True, True)):
+        if overlap and kind != "sage":
+            out.append(out[-1])
+            continue
+        t = Trainer(indptr, indices, feats, labels, 5, rank=0, world=1, fanouts=(10, 5), batch=128, streams=2,
+                    hidden=16, lr=1e-2, dist=dist, model=kind, heads=2, rank_path=rank_path, overlap=overlap)
+        t.set_nodes(perm)
+        out.append(t.run(4))
+        t.close()
+
+
+@pytest.mark.parametrize("kind", ["sage", "gat"])
+def test_rccl_calls_on_one_gpu(kind):
+    """The one-process-per-part code path with the REAL backend (nccl = RCCL) and a world of one: the
+    all_to_all_single / all_reduce calls, their device tensors and their empty splits go through RCCL, and the
+    losses equal the collective-free single-part path."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single_rank, args=(_free_port(), q, kind))
+    p.start()
+    got = q.get(timeout=240)
+    p.join(timeout=120)
+    assert got[0] != "error", got[1]
+    plain, ranked, overlapped = got
+    assert p.exitcode == 0
+    np.testing.assert_allclose(ranked, plain, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(overlapped, plain, rtol=1e-5, atol=1e-6)   # side-stream exchange schedule (SAGE)
