@@ -331,6 +331,9 @@ def main():
                     out["roofline"]["traffic"] = 1024.0 * (2.0 * pmc["fetch_KiB_sum"][dom] + pmc["write_KiB_sum"][dom]) / calls
                     out["roofline"]["traffic_source"] = ("profiles/%s/pmc.json (2 x FETCH_SIZE + WRITE_SIZE; all read "
                                                          "requests are 128 B: profiles/pmc_rdsize.sh)" % latest)
+                    out["roofline"]["traffic_note"] = (
+                        "traffic above the algorithmic bytes is whole 128-B lines fetched for 4-20-byte random gathers "
+                        "(neighbour picks in `indices`, row lookups), not re-reads: DESIGN.md section 6, Request budget")
             except Exception:
                 pass
             out["kernels"] = per_kernel
