@@ -436,6 +436,13 @@ def main():
             finished.set()
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        # every rank got here (a failed e2e leg leaves through os._exit above): orderly shutdown of the group
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
