@@ -216,7 +216,8 @@ __global__ __launch_bounds__(TN) void k_seeds(const long long* __restrict__ node
   if (i == 0) {
     fsize[s * (CSL_MAX_LAYERS + 1)] = (uint32_t)d.count;
     for (int l = 1; l <= n_layers; l++) fsize[s * (CSL_MAX_LAYERS + 1) + l] = 0;
-    meta[s].error = 0;
+    // (meta[s].error was zeroed by a memset on the stream before this launch: a reset in here would race
+    // with the other blocks' atomicOr of CSL_ERR_SEED_RANGE)
     meta[s].n_seeds = (uint32_t)d.count;
   }
   if (i < (uint32_t)d.count) {
@@ -1751,6 +1752,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
   HIPCHECK(hipEventRecord(e->desc_event[slot], st));
   e->desc_inflight[slot] = 1;
   csl_sample_meta* meta = e->meta + (size_t)slot * S;
+  HIPCHECK(hipMemsetAsync(meta, 0, sizeof(csl_sample_meta) * (size_t)S, st));  // error bits and stale layer tables
   {
     Timed t(e, KN_SEEDS, st);
     dim3 grid((unsigned)((e->fcap[0] + TN - 1) / TN), S);

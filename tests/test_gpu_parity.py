@@ -65,6 +65,22 @@ def test_duplicate_and_bad_seeds_fail_loudly(abi):
     with pytest.raises(abi.CslError):
         e.meta(0)
     e.close()
+    # an out-of-range id deep inside a multi-tile batch, in any stream, several rounds in a row (the error
+    # bits are cleared by a memset before the round, never by the kernel that may be setting them)
+    n = indptr.shape[0] - 1
+    e = abi.Engine(indptr, indices, max_batch=1024, n_streams=3, n_slots=2)
+    good = (np.arange(1024) % n).astype(np.int64)
+    # (ids repeat here, which raises DUP_SEED for every stream; the range bit must be there only for stream 1)
+    bad = good.copy()
+    bad[700] = n + 5
+    for r in range(3):
+        e.submit_seeds([good, bad, good], slot=r & 1)
+        for st, want in ((0, False), (1, True), (2, False)):
+            with pytest.raises(abi.CslError) as ei:
+                e.meta(st, r & 1)
+            bits = int(str(ei.value).split("bits ")[1].split()[0], 16)
+            assert bool(bits & 4) == want, "round %d stream %d: %s" % (r, st, ei.value)
+    e.close()
 
 
 def _rand_graph(n, mean_deg, seed):
