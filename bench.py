@@ -9,11 +9,20 @@ own mt19937(5489)).  One *step* = one round = S minibatches sliced in the same
 kernel launches.  Inputs (CSR, node permutation, mt19937 window) are resident
 in HBM before the timed region.
 
-Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL, used
-only for the barrier and the max-over-ranks).  The path shards by minibatch:
-rank r slices its own minibatches, no data-path collective ("weak" scaling).
+Multi-GPU: one process per GPU (torch.distributed, backend nccl == RCCL).  The
+slicer shards by minibatch: rank r slices its own minibatches, no data-path
+collective ("weak" scaling; `value`).  The split-parallel training step that
+consumes the slices (one part per GPU, RCCL all-to-all of boundary partial sums
+per layer + gradient all-reduce) runs after it on the same ranks and is reported
+as `e2e` / `e2e_iters_per_sec` ("strong" scaling of one global minibatch).
 
-Prints ONE JSON line on rank 0.
+Launch forms: under torch.distributed.run (RANK/WORLD_SIZE in the environment)
+this process is one rank.  `python bench.py --gpus N` with N > 1 and no
+WORLD_SIZE starts the N ranks itself as a CHILD torch.distributed.run (decided
+before anything here imports torch or touches the GPU) and relays rank 0's line.
+
+Prints ONE JSON line on rank 0.  Exit code: 0 only if every leg finished; a
+failed or timed-out e2e leg still prints the line (with `e2e.error`) and exits 3.
 """
 import argparse
 import json
@@ -65,6 +74,9 @@ def parse():
     ap.add_argument("--e2e-hidden", type=int, default=256)
     ap.add_argument("--e2e-feat", type=int, default=100)
     ap.add_argument("--e2e-classes", type=int, default=47)
+    ap.add_argument("--selftest-dist", choices=("ok", "e2e-fail", "e2e-hang"), default=None,
+                    help="no GPU work at all: rendezvous (gloo), reductions, the guarded e2e leg with a stand-in body, "
+                         "the single JSON line and the shutdown path -- what tests/test_bench_launch.py runs on CPU")
     return ap.parse_args()
 
 
@@ -136,12 +148,187 @@ def kernel_bytes_device_layout(name, m, P, layer=0, last=False):
     return 0
 
 
+def launch_plan(gpus, env):
+    """How this invocation runs: ("rank", world) when it is one rank of a job somebody else launched (or the
+    single-GPU case), ("spawn", gpus) when it has to start the ranks itself."""
+    if "WORLD_SIZE" in env:
+        return "rank", int(env["WORLD_SIZE"])
+    if gpus > 1:
+        return "spawn", gpus
+    return "rank", 1
+
+
+def self_launch(gpus, argv):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as a child
+    process tree.  The parent has not imported torch and never touches the GPU; rank 0's JSON line goes
+    straight to the inherited stdout.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write("[bench] --gpus %d without WORLD_SIZE: launching %s\n" % (gpus, " ".join(cmd[1:9])))
+    return subprocess.call(cmd)
+
+
+E2E_FAILED_RC = 3
+
+
+def run_guarded(leg, out, rank, world, timeout, store=None):
+    """Run the multi-rank e2e leg under a watchdog.  On success rank 0 gets the result in out["e2e"].  If the leg
+    raises on some rank, or does not finish within `timeout` seconds (a collective some other rank never joined),
+    rank 0 prints the line with `e2e.error` and every process exits with E2E_FAILED_RC -- never 0: the process
+    group may be wedged, so there is no orderly shutdown on that path.
+
+    torch.distributed.run kills the surviving ranks as soon as one exits non-zero, so a failing rank other than 0
+    first tells rank 0 through the rendezvous store (`store`, a c10d Store) and waits for its acknowledgement
+    (the line is out) before it leaves; the watchdogs poll the store, so nobody sits out the whole timeout."""
+    import threading
+    finished = threading.Event()
+    k_fail, k_ack = "bench_e2e_failed", "bench_e2e_line_printed"
+
+    def store_do(fn, default=None):
+        try:
+            return fn() if store is not None else default
+        except Exception:
+            return default
+
+    def give_up(msg):
+        if rank == 0:
+            out["e2e"] = {"error": msg}
+            out["e2e_iters_per_sec"] = None
+            sys.stdout.write(json.dumps(out) + "\n")
+            sys.stdout.flush()
+            store_do(lambda: store.set(k_ack, "1"))
+            time.sleep(0.5)      # let the others read the acknowledgement before the launcher reaps everybody
+        else:
+            store_do(lambda: store.set(k_fail, "rank %d: %s" % (rank, msg)))
+            t_end = time.time() + 30.0
+            while store is not None and time.time() < t_end and not store_do(lambda: store.check([k_ack]), True):
+                time.sleep(0.1)
+        sys.stderr.write("[bench] rank %d: e2e leg failed: %s\n" % (rank, msg))
+        sys.stderr.flush()
+        os._exit(E2E_FAILED_RC)
+
+    def watchdog():
+        t_end = time.time() + timeout
+        while not finished.wait(0.25):
+            if store_do(lambda: store.check([k_fail]), False):
+                give_up(store_do(lambda: store.get(k_fail).decode(), "a peer rank failed"))
+            if time.time() > t_end:
+                give_up("the %d-GPU e2e leg did not finish within %.0f s" % (world, timeout))
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        res = leg()
+    except Exception as ex:  # (the collective of a rank whose peer left may raise too: same exit)
+        give_up(repr(ex)[:300])
+    finished.set()
+    if rank == 0:
+        out["e2e"] = res
+
+
+def default_store(dist):
+    try:
+        return dist.distributed_c10d._get_default_store()
+    except Exception:
+        return None
+
+
+def finish(out, rank, dist):
+    """Rank 0 prints the single JSON line; then ONE barrier and the process group goes."""
+    if rank == 0 and "iters_per_sec" in (out.get("e2e") or {}):
+        # first-class: the end-to-end half of the headline metric (strong scaling on several GPUs)
+        out["e2e_iters_per_sec"] = out["e2e"]["iters_per_sec"]
+        out["e2e_scaling"] = "strong" if out.get("n_gpus", 1) > 1 else None
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def selftest_dist(args, rank, world):
+    """--selftest-dist: the distributed plumbing of this script with no GPU in sight (gloo)."""
+    import torch.distributed as dist
+    from cslicer import shard
+    dist.init_process_group(backend="gloo")
+    dt = shard.max_over_ranks(0.001 * (rank + 1), dist, "cpu")
+    units = shard.sum_over_ranks(10.0, dist, "cpu")
+    out = {"metric": "selftest", "n_gpus": world, "value": units / dt, "selftest": args.selftest_dist,
+           "dist": {"backend": dist.get_backend(), "world_size": dist.get_world_size()}}
+
+    def leg():
+        if args.selftest_dist == "e2e-fail" and rank == world - 1:
+            raise RuntimeError("stand-in failure on rank %d" % rank)
+        if args.selftest_dist == "e2e-hang" and rank == world - 1:
+            time.sleep(3600)
+        dist.barrier()       # the others wait in a collective, as they would in the real leg
+        return {"iters_per_sec": 1.0}
+
+    if world > 1:
+        run_guarded(leg, out, rank, world, args.e2e_timeout, default_store(dist))
+    else:
+        out["e2e"] = leg()
+    finish(out, rank, dist)
+
+
+
+def host_cpu_info():
+    """CPU model, physical/logical core counts and the CPUs this process may actually use (affinity mask and
+    cgroup quota): what the cpu_baseline leg runs on (BASELINE.md section 2 asks for model and core count)."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    if quota:
+        usable = max(1, min(usable, int(quota + 0.5)))
+    return {"model": model, "logical_cpus": logical, "physical_cores": len(phys) or None,
+            "usable_cpus": usable, "cgroup_cpu_quota": quota}
+
+
 def main():
     args = parse()
+    how, world = launch_plan(args.gpus, os.environ)
+    if how == "spawn":
+        sys.exit(self_launch(world, sys.argv[1:]))
     fan = tuple(int(x) for x in args.fanout.split(","))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.selftest_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        return selftest_dist(args, rank, world)
     import torch
     dist = None
     ndev = torch.cuda.device_count()
@@ -351,7 +538,8 @@ def main():
         # ---- CPU baseline: the oracle (port of the reference algorithm) on host cores
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as orc
-            cores = min(16, os.cpu_count() or 1)
+            host = host_cpu_info()
+            cores = host["usable_cpus"]      # every CPU this process may use (affinity mask / cgroup quota)
             probe = [perm[i * B:(i + 1) * B] for i in range(2)]
             sec1, e1 = orc.bench(indptr, indices, probe, n_parts=P, fanouts=fan, threads=1)
             per_iter_s = sec1 / 2
@@ -364,6 +552,7 @@ def main():
                 "sample": "%d minibatches of the same workload (first %d of the permutation), %d threads, one "
                           "slicer per thread, incl. per-sample deep copy; %.2fs" % (nb, nb, cores, secT),
                 "iters_per_sec": nb / secT,
+                "host": host,
                 "single_thread": {"value": e1 / sec1, "iters_per_sec": 2 / sec1, "sample": "2 minibatches"},
             }
             secN, eN = orc.bench(indptr, indices, sample, n_parts=P, fanouts=fan, threads=cores, deep_copy=False)
@@ -404,48 +593,19 @@ def main():
     if eng is not None:
         eng.close()
         eng = None
-    # The e2e leg runs LAST, and on several GPUs under a watchdog: its RCCL exchange (all_to_all_single per
-    # layer + gradient all-reduce) has only been rehearsed over gloo in this round, and a collective that never
-    # completes must not take the slicer's result with it.  Rank 0 then prints the line without an e2e rate.
+    # The e2e leg runs LAST.  On several GPUs it is a job of RCCL collectives (all_to_all_single per layer +
+    # gradient all-reduce) and runs under a watchdog: a collective that never completes, or a rank that raises,
+    # must not take the slicer's result with it, and must not look like a success either.  Rank 0 then prints
+    # the line with `e2e.error` and EVERY rank leaves with a non-zero code (torch.distributed.run reports it).
+    if dist is not None:
+        out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                       "launcher": "torch.distributed.run"}
     if args.e2e_steps > 0 and (world == 1 or not args.no_e2e_multi):
         if world == 1:
             out["e2e"] = e2e_leg()
         else:
-            import threading
-            finished = threading.Event()
-
-            def watchdog():
-                if not finished.wait(args.e2e_timeout):
-                    if rank == 0:
-                        out["e2e"] = {"error": "the %d-GPU e2e leg did not finish within %.0f s" % (world, args.e2e_timeout)}
-                        sys.stdout.write(json.dumps(out) + "\n")
-                        sys.stdout.flush()
-                    os._exit(0)
-
-            threading.Thread(target=watchdog, daemon=True).start()
-            try:
-                res = e2e_leg()
-                if rank == 0:
-                    out["e2e"] = res
-            except Exception as ex:  # this rank leaves; the others' watchdogs release them
-                if rank == 0:
-                    out["e2e"] = {"error": repr(ex)[:300]}
-                    sys.stdout.write(json.dumps(out) + "\n")
-                    sys.stdout.flush()
-                os._exit(0)
-            finished.set()
-    if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
-    if dist is not None:
-        # every rank got here (a failed e2e leg leaves through os._exit above): orderly shutdown of the group
-        try:
-            dist.destroy_process_group()
-        except Exception:
-            pass
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            run_guarded(e2e_leg, out, rank, world, args.e2e_timeout, default_store(dist))
+    finish(out, rank, dist)
 
 
 if __name__ == "__main__":

@@ -107,9 +107,13 @@ def test_pyfront():
 
 
 def test_list(l):
-    """testlist (pyfrontend.cpp:94-109): returns [1,2,3,4]; the append(10) lands
-    on the caster's temporary copy of the argument, which the caller never sees."""
-    list(l).append(10)
+    """testlist (pyfrontend.cpp:94-109): returns [1,2,3,4] and appends 10 to the CALLER's list (`py::list l` is
+    a handle to the argument, pyfrontend.cpp:107; verified on the compiled reference: [7,8] -> [7,8,10]).
+    Like pybind11's py::list parameter it accepts a list only."""
+    if not isinstance(l, list):
+        raise TypeError("test_list(): incompatible function arguments. The following argument types are supported:\n"
+                        "    1. (arg0: list) -> list")
+    l.append(10)
     return [1, 2, 3, 4]
 
 

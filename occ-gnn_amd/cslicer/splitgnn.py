@@ -241,7 +241,7 @@ class DistSageConv(nn.Module):
         cat = torch.cat([self_h, neigh], dim=1)
         # The row count is different in every minibatch, and hipBLASLt pays a heuristic search for every
         # GEMM shape it has not seen (80 us instead of 25 us of host time per call, three GEMMs per layer
-        # with backward: profiles/gemm_shape_test.py).  Rounding the rows up makes the shapes repeat.
+        # with backward: profiles/gemm_shape_probe.py).  Rounding the rows up makes the shapes repeat.
         m = cat.shape[0]
         mp = (m + ROW_PAD - 1) // ROW_PAD * ROW_PAD
         if m >= ROW_PAD:

@@ -466,7 +466,7 @@ class CSlicer {
 py::list testlist(py::list l) {  // pyfrontend.cpp:94-109
   std::vector<int> v = {1, 2, 3, 4};
   py::list out = py::cast(v);
-  (void)l;  // the reference appends 10 to the caster's temporary copy, invisible to the caller
+  l.append(10);  // py::list is a handle to the CALLER's list: the append is visible to the caller (pyfrontend.cpp:107)
   return out;
 }
 

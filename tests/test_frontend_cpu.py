@@ -29,9 +29,14 @@ def test_test_pyfront_and_test_list():
                       "self_ids_in", "self_ids_out"):
                 assert getattr(b, n) == []
             assert b.from_ids == [[], [], [], []] and b.to_ids == [[], [], [], []]
-    arg = [1, 2, 3]
+    # pyfrontend.cpp:107: `l.append(10)` acts on a py::list HANDLE, i.e. on the caller's list
+    # (checked on the compiled reference module: test_list([7, 8]) leaves the caller's list [7, 8, 10])
+    arg = [7, 8]
     assert cslicer.test_list(arg) == [1, 2, 3, 4]
-    assert arg == [1, 2, 3]
+    assert arg == [7, 8, 10]
+    import pytest
+    with pytest.raises(TypeError):
+        cslicer.test_list((1, 2))        # pybind11's py::list parameter takes a list only
 
 
 def test_bipatite_attribute_value_semantics():
@@ -111,8 +116,8 @@ def test_native_pybind_module_surface():
     got = b.in_nodes
     got.append(6)
     assert b.in_nodes == [4, 5]
-    arg = [1, 2, 3]
-    assert m.test_list(arg) == [1, 2, 3, 4] and arg == [1, 2, 3]
+    arg = [7, 8]
+    assert m.test_list(arg) == [1, 2, 3, 4] and arg == [7, 8, 10]   # pyfrontend.cpp:107 mutates the caller's list
     import inspect
     doc = m.cslicer.__init__.__doc__
     for a in ("name", "queue_size", "no_worker_threads", "number_of_epochs", "minibatch_size"):
