@@ -37,7 +37,7 @@ extern "C" {
 
 #define CSL_MAX_PARTS 8
 #define CSL_MAX_LAYERS 4
-#define CSL_ABI_VERSION 2
+#define CSL_ABI_VERSION 3
 
 enum {
   CSL_OK = 0,
@@ -51,7 +51,9 @@ enum {
 /* bits of csl_sample_meta.error (set by the kernels, never silently ignored) */
 enum {
   CSL_ERR_RNG_WINDOW = 1,     /* a draw fell outside the generated mt19937 window */
-  CSL_ERR_DUP_SEED = 2,       /* repeated seed id in one minibatch (unsupported) */
+  CSL_ERR_DUP_SEED = 2,       /* repeated seed id in one minibatch, CSL_MODE_GRAPH only (its specification is
+                                 defined for distinct seeds); CSL_MODE_STRICT follows the reference:
+                                 every occurrence is sampled, the lists are merged as bipartite.cpp:3-17 does */
   CSL_ERR_SEED_RANGE = 4,     /* seed id outside [0, num_nodes) */
   CSL_ERR_FRONTIER_CAP = 8,   /* a frontier outgrew its configured capacity */
   CSL_ERR_BUCKET_FULL = 16    /* an LDS dedup bucket overflowed (hash skew) */
@@ -98,7 +100,7 @@ typedef struct {
   int32_t device;            /* HIP device ordinal */
   /* graph: the reference's Dataset arrays (dataset.h:39-40), host memory */
   int64_t num_nodes;
-  int64_t num_edges;
+  int64_t num_edges;         /* < 2^40 (the reference's `int offset`, slicer.cpp:9, is only defined below 2^31) */
   const int64_t* indptr;     /* [num_nodes + 1] */
   const int64_t* indices;    /* [num_edges] */
   const int32_t* workload;   /* [num_nodes] owner part of each node, or NULL => v % n_parts
@@ -121,7 +123,11 @@ typedef struct {
 enum {
   /* run every round on one HIP stream (no overlap of consecutive rounds): per-kernel
    * durations are then not stretched by a neighbouring round; used for profiling */
-  CSL_FLAG_SERIAL_ROUNDS = 1
+  CSL_FLAG_SERIAL_ROUNDS = 1,
+  /* keep every layer's raw neighbour_sample stream (slicer.cpp:6-22: the node itself, then its sampled
+   * neighbours, sampled self loops included) per result slot for csl_copy_candidates; test/debug only:
+   * costs n_slots x n_layers x n_streams x (largest candidate capacity) x 4 bytes of device memory */
+  CSL_FLAG_KEEP_CANDIDATES = 2
 };
 
 typedef struct {
@@ -217,6 +223,13 @@ int csl_frontier_device_ptr(csl_engine* e, int32_t slot, int32_t stream, int32_t
 int64_t csl_copy_frontier(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int64_t* dst,
                           int64_t cap);
 
+/* Slicer::neighbour_sample's output vectors (slicer.cpp:6-22), the pre-dedup edge stream of `layer`: for every
+ * frontier node in order its `neighbors` vector (the node itself first), concatenated into flat[], lengths in
+ * counts[] (one per frontier node).  Needs CSL_FLAG_KEEP_CANDIDATES.  Returns the number of ids written to
+ * flat, or a negative error.  (Debug/parity export: the reference itself never exports the stream.) */
+int64_t csl_copy_candidates(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int64_t* flat,
+                            int64_t cap_flat, int64_t* counts, int64_t cap_counts);
+
 /* HIP stream (a hipStream_t) the rounds of result slot `slot` are launched on, for callers
  * that order their own work after a round.  With >= 2 slots, rounds alternate between two
  * streams (and two scratch sets) so that consecutive rounds overlap on the GPU. */
@@ -224,7 +237,7 @@ int csl_hip_stream(csl_engine* e, int32_t slot, void** out);
 
 /* time the dominant kernels of the last rounds with HIP events on the
  * engine's own stream: enable, run rounds, read back per-kernel totals */
-#define CSL_NUM_KERNELS 13
+#define CSL_NUM_KERNELS 14
 int csl_timing_enable(csl_engine* e, int32_t on);
 int csl_timing_read(csl_engine* e, double* ms_total /*[CSL_NUM_KERNELS]*/,
                     int64_t* launches /*[CSL_NUM_KERNELS]*/);

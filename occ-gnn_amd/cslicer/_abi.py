@@ -14,13 +14,14 @@ LIB_PATH = os.environ.get("CSLICER_LIB") or os.path.join(os.path.dirname(HERE), 
 
 MAX_PARTS = 8
 MAX_LAYERS = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 NUM_LISTS = 10
-NUM_KERNELS = 13
+NUM_KERNELS = 14
 (IN_NODES, OUT_NODES, OWNED_OUT_NODES, SELF_IDS_IN, SELF_IDS_OUT, TO_IDS, FROM_IDS,
  INDPTR, INDICES, OWNED_DEGREE) = range(10)
 MODE_STRICT, MODE_GRAPH = 0, 1
 FLAG_SERIAL_ROUNDS = 1
+FLAG_KEEP_CANDIDATES = 2
 LIST_KINDS = {
     "in_nodes": IN_NODES, "out_nodes": OUT_NODES, "owned_out_nodes": OWNED_OUT_NODES,
     "self_ids_in": SELF_IDS_IN, "self_ids_out": SELF_IDS_OUT, "to_ids": TO_IDS, "from_ids": FROM_IDS,
@@ -33,7 +34,7 @@ SYMBOLS = [
     "csl_submit_round", "csl_submit_seeds", "csl_sync", "csl_get_meta", "csl_copy_list",
     "csl_list_device_ptr", "csl_frontier_device_ptr", "csl_copy_frontier", "csl_hip_stream",
     "csl_timing_enable", "csl_timing_read", "csl_kernel_name", "csl_rng_peek", "csl_device_bytes",
-    "csl_fetch_sample", "csl_fetch_sample32", "csl_totals", "csl_arena_info",
+    "csl_fetch_sample", "csl_fetch_sample32", "csl_totals", "csl_arena_info", "csl_copy_candidates",
 ]
 
 
@@ -121,6 +122,8 @@ def load():
     L.csl_copy_frontier.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, p64, C.c_int64]
     L.csl_copy_frontier.restype = C.c_int64
     L.csl_hip_stream.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.csl_copy_candidates.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, p64, C.c_int64, p64, C.c_int64]
+    L.csl_copy_candidates.restype = C.c_int64
     L.csl_timing_enable.argtypes = [vp, C.c_int32]
     L.csl_timing_read.argtypes = [vp, C.POINTER(C.c_double), p64]
     L.csl_kernel_name.argtypes = [C.c_int32]
@@ -179,6 +182,7 @@ class Engine:
         cfg.mode = mode
         cfg.flags = flags
         self.mode = mode
+        self.flags = flags
         if frontier_cap is not None:
             for l, c in enumerate(frontier_cap):
                 cfg.frontier_cap[l] = int(c)
@@ -244,6 +248,17 @@ class Engine:
                                               out.ctypes.data_as(C.POINTER(C.c_int64)), out.shape[0]))
         return out[:got]
 
+    def copy_candidates(self, layer, stream=0, slot=0, meta=None):
+        """(flat, counts): the layer's raw neighbour_sample stream (needs flags=FLAG_KEEP_CANDIDATES)."""
+        m = meta if meta is not None else self.meta(stream, slot)
+        F = int(m.layer[layer].frontier)
+        flat = np.empty(max(F * (self.fanouts[layer] + 1), 1), dtype=np.int64)
+        counts = np.empty(max(F, 1), dtype=np.int64)
+        n = _check(load().csl_copy_candidates(self._h, slot, stream, layer, flat.ctypes.data_as(C.POINTER(C.c_int64)),
+                                              flat.shape[0], counts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                              counts.shape[0]))
+        return flat[:n], counts[:F]
+
     def list_device_ptr(self, layer, kind, stream=0, slot=0):
         p = C.c_void_p()
         _check(load().csl_list_device_ptr(self._h, slot, stream, layer, kind, C.byref(p)))
@@ -305,6 +320,12 @@ class Engine:
             out["frontier"].append(self.copy_frontier(l, stream, slot, m))
         out["draws_total"] = int(m.rng_end)
         out["rng_begin"] = int(m.rng_begin)
+        if self.flags & FLAG_KEEP_CANDIDATES:
+            out["nbr_flat"], out["nbr_counts"] = [], []
+            for l in range(self.n_layers):
+                flat, counts = self.copy_candidates(l, stream, slot, m)
+                out["nbr_flat"].append(flat)
+                out["nbr_counts"].append(counts)
         return out
 
     def graph_dict(self, stream=0, slot=0):

@@ -91,11 +91,11 @@ __host__ __device__ constexpr int NKINDS(int P, bool graph) { return graph ? 3 +
 constexpr int MAXK = 3 + 7 * CSL_MAX_PARTS + CSL_MAX_PARTS * CSL_MAX_PARTS;
 
 enum { KN_SEEDS = 0, KN_DEGREE, KN_SCAN_A, KN_SAMPLE, KN_SCAN_Q, KN_SCATTER, KN_BUCKET, KN_COUNT, KN_SCAN_B,
-       KN_EMIT, KN_SELFIN, KN_MT, KN_EDGES };
+       KN_EMIT, KN_SELFIN, KN_MT, KN_EDGES, KN_DUPSEEDS };
 const char* const kKernelNames[CSL_NUM_KERNELS] = {"k_seeds",   "k_degree", "k_scan_need", "k_sample",
                                                    "k_scan_buckets", "k_scatter", "k_bucket", "k_count",
                                                    "k_scan_lists", "k_emit",  "k_selfin",  "k_mt19937_fill",
-                                                   "k_graph"};
+                                                   "k_graph", "k_dupseeds"};
 
 // Everything a layer's kernels need; passed by value.
 struct LArgs {
@@ -144,6 +144,15 @@ struct LArgs {
   uint32_t S;
   uint32_t tpb;               // frontier tiles per k_sample block
   uint32_t last;              // 1 on the final layer (no next frontier to prepare)
+  // repeated seed ids (layer 0 only; bipartite.cpp:3-17 on a batch with duplicates): see k_dupseeds
+  uint32_t* dupflag;          // [S] != 0: the stream's minibatch holds a seed id more than once
+  uint32_t* seedrep;          // [S][fcap0] index of the first seed with the same id
+  uint32_t* dupfirst;         // [S][fcap0*P] scratch of k_dupseeds
+  uint32_t* dupout;           // [S][fcap0*P] scratch of k_dupseeds
+  size_t fcap0;
+  unsigned long long* rngend; // [S] the stream's mt19937 position after this round (per scratch set)
+  // CSL_FLAG_KEEP_CANDIDATES: raw neighbour_sample stream of this layer, [S][ccap] (debug export)
+  uint32_t* candk;
   // CSL_MODE_GRAPH extras
   uint32_t graph;             // 0 strict, 1 graph
   uint8_t* ecnt;              // [S][fcap*P] edges of node i whose source is owned by g
@@ -209,13 +218,14 @@ struct BatchDesc {
 
 __global__ __launch_bounds__(TN) void k_seeds(const long long* __restrict__ nodes, const BatchDesc* __restrict__ desc,
                                               uint32_t* fr0, size_t fr0_stride, uint32_t* fsize,
-                                              csl_sample_meta* meta, uint32_t N, int n_layers) {
+                                              csl_sample_meta* meta, uint32_t N, int n_layers, uint32_t* dupflag) {
   const int s = blockIdx.y;
   const BatchDesc d = desc[s];
   const uint32_t i = blockIdx.x * TN + threadIdx.x;
   if (i == 0) {
     fsize[s * (CSL_MAX_LAYERS + 1)] = (uint32_t)d.count;
     for (int l = 1; l <= n_layers; l++) fsize[s * (CSL_MAX_LAYERS + 1) + l] = 0;
+    dupflag[s] = 0;  // set by k_bucket of layer 0, read by k_dupseeds: both later launches on this HIP stream
     // (meta[s].error was zeroed by a memset on the stream before this launch: a reset in here would race
     // with the other blocks' atomicOr of CSL_ERR_SEED_RANGE)
     meta[s].n_seeds = (uint32_t)d.count;
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(PHASE == 0 ? TN : SCAN_T) void k_scan(LArgs a) {
       const unsigned long long draws = (unsigned long long)s_tot[K_NEED] * a.fanout;
       a.rngbase[s] = base;
       a.rngpos[s] = base + draws;
+      a.rngend[s] = base + draws;  // per scratch set: what the round's position snapshot copies
       if (a.layer == 0) a.meta[s].rng_begin = base;
       a.meta[s].rng_end = base + draws;
       a.acc[2 * s] += s_tot[K_EDGES];
@@ -583,6 +594,7 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
             if (val[u] == vvu[u]) {
               // a sampled self loop only re-adds the self edge (slicer.cpp:33-35,
               // bipartite.h:34): it is neither an edge nor new to the frontier
+              if (a.candk) a.candk[cbase + k0 + u * TN] = val[u];  // (the raw stream keeps it)
               val[u] = UNSET;
             } else {
               const uint32_t og = owner(a, val[u]);
@@ -593,6 +605,7 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
           }
           a.cand[cbase + k0 + u * TN] = val[u];
           a.cflag[cbase + k0 + u * TN] = 0;  // k_bucket overwrites the flags of real candidates
+          if (a.candk && (val[u] != UNSET || slu[u] == 0 || !gat[u])) a.candk[cbase + k0 + u * TN] = val[u];
         }
       }
     }
@@ -826,8 +839,13 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
   // what an entry leaves in its slot: the self entry its frontier index, an edge entry its position (min)
   auto record = [&](const uint2 ee, const uint32_t h) {
     if (ee.y & SELF_BIT) {
-      // only the seed layer can hold a node twice
-      if (atomicExch(&h_self[h], ee.y & ~SELF_BIT) != UNSET) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
+      // h_self = the node's FIRST frontier index.  Only the seed layer can hold a node twice (later frontiers
+      // are deduplicated): strict mode then follows bipartite.cpp:3-17 (k_dupseeds); graph mode, whose
+      // specification is only defined for distinct seeds, refuses the minibatch.
+      if (atomicMin(&h_self[h], ee.y & ~SELF_BIT) != UNSET) {
+        if (a.graph) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
+        else a.dupflag[s] = 1u;
+      }
       // graph mode: the self entry is a source of its own slice
       if (a.graph) atomicMin(&h_epos[h], (ee.y & ~SELF_BIT) * W);
     } else {
@@ -856,8 +874,11 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
         const uint32_t fe = epos == c;  // epos already includes the self entry
         if (fe) cflag[c] = (uint8_t)(fe | (fe << 1) | (g << 2));
       } else {
-        const uint32_t newf = epos > c;  // UNSET compares greater than any position
+        // new to the frontier: no edge occurrence before it (UNSET compares greater than any position) and,
+        // for a repeated seed id, the first of its self entries (slicer.cpp:45-49)
+        const uint32_t newf = epos > c && self == i;
         if (newf) cflag[c] = (uint8_t)(newf | (g << 2));
+        if (a.layer == 0) a.seedrep[s * a.fcap0 + i] = self;
       }
       a.firstpos[s * a.fcap + i] = epos;
     } else {
@@ -1197,6 +1218,153 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
 #undef BYTESUM
 }
 
+// ---- k_dupseeds (strict mode, layer 0, only for a minibatch that holds a seed id more than once): the
+// node-level lists of BiPartite::reorder (bipartite.cpp:10-16) for a frontier WITH repeated ids.  The
+// reference samples every occurrence (its own draws), and then
+//   * out_nodes of slice g keeps the FIRST occurrence of an id among the entries with an edge from g
+//     (order_and_remove_duplicates, duplicate.cpp:14-26),
+//   * owned_out_nodes / self_ids_* / to_ids / from_ids keep one entry per push; a push is skipped when the
+//     previous push to the SAME list carried the same id (bipartite.h:33-66 `back() == nd1`), i.e. when the
+//     previous member entry of that list is another occurrence of the id,
+//   * every value is replace()d by the id's index in the slice's out_nodes, or -1 (duplicate.cpp:35-39):
+//     ALL occurrences of an id point to the same out-node, whichever occurrence pushed it.
+// With distinct seeds this is what k_emit wrote (no skip ever applies, every entry is its own first
+// occurrence), so k_emit's lists stand and this kernel returns at once.  Otherwise it rewrites the five
+// node-level lists of the stream's layer 0 (they only get shorter) and their offsets in the meta.
+// One block per stream; entries are walked in chunks of DS_T with carried scans.  in_nodes, self_ids_in's
+// values and the next frontier do not depend on it (k_bucket / k_emit / k_selfin).
+constexpr int DS_T = 256;
+__device__ __forceinline__ uint32_t ds_ld(const uint32_t* p) {
+  // written earlier in this kernel by other threads (plain stores or L2 atomics): read past the vector L1
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// exclusive block scan of one value per thread; IS_MAX: running maximum (identity 0), else sum
+template <bool IS_MAX>
+__device__ __forceinline__ uint32_t ds_block_scan(uint32_t x, uint32_t* s_w, uint32_t& total) {
+  const uint32_t lane = lane_id(), w = threadIdx.x >> 6;
+  uint32_t incl = x;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(incl, o);
+    if ((int)lane >= o) incl = IS_MAX ? (incl > y ? incl : y) : incl + y;
+  }
+  uint32_t excl = __shfl_up(incl, 1);
+  if (lane == 0) excl = 0;
+  __syncthreads();  // s_w free again
+  if (lane == 63) s_w[w] = incl;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+  for (uint32_t k = 0; k < DS_T / 64; k++) {
+    const uint32_t t = s_w[k];
+    if (k < w) before = IS_MAX ? (before > t ? before : t) : before + t;
+    all = IS_MAX ? (all > t ? all : t) : all + t;
+  }
+  total = all;
+  return IS_MAX ? (excl > before ? excl : before) : excl + before;
+}
+
+__global__ __launch_bounds__(DS_T) void k_dupseeds(LArgs a) {
+  const uint32_t s = blockIdx.x;
+  if (!a.dupflag[s]) return;
+  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1)], P = a.P, n = threadIdx.x;
+  const uint32_t* fr = a.fr_in + s * a.fr_in_stride;
+  const uint32_t* hbv = a.hasedge + s * a.fcap;
+  const uint32_t* rep = a.seedrep + s * a.fcap0;
+  uint32_t* firstg = a.dupfirst + (size_t)s * a.fcap0 * P;  // [entry][part] first occurrence with an edge from g
+  uint32_t* outidx = a.dupout + (size_t)s * a.fcap0 * P;    // [entry][part] its index in out_nodes of g
+  uint32_t* selfpos = a.selfpos + s * a.fcap;
+  int* ar = a.arena + (size_t)s * a.arena_stride;
+  csl_layer_meta& m = a.meta[s].layer[0];
+  __shared__ uint32_t s_w[DS_T / 64];
+  __shared__ uint32_t s_cnt[5][CSL_MAX_PARTS];  // kinds OUT, OWNED, SELF, TO, FROM
+  __shared__ uint32_t s_off[5][CSL_MAX_PARTS + 1];
+  for (uint32_t k = n; k < F * P; k += DS_T) firstg[k] = UNSET;
+  __syncthreads();
+  for (uint32_t i = n; i < F; i += DS_T) {
+    const uint32_t h = hbv[i], r = rep[i];
+    for (uint32_t g = 0; g < P; g++)
+      if ((h >> g) & 1u) atomicMin(&firstg[(size_t)r * P + g], i);
+  }
+  __syncthreads();
+  const uint32_t chunks = (F + DS_T - 1) / DS_T;
+  // pass 0: out_nodes indices and the size of every list; pass 1: the lists
+  for (int pass = 0; pass < 2; pass++) {
+    for (uint32_t g = 0; g < P; g++) {
+      for (int kind = pass == 0 ? 0 : 1; kind < 5; kind++) {
+        uint32_t run = 0, prev_run = 0;  // carried over the chunks: members so far, last member entry + 1
+        for (uint32_t ch = 0; ch < chunks; ch++) {
+          const uint32_t i = ch * DS_T + n;
+          const bool act = i < F;
+          uint32_t v = 0, h = 0, r = 0, to = 0;
+          if (act) {
+            v = fr[i];
+            h = hbv[i];
+            r = rep[i];
+            to = owner(a, v);
+          }
+          const bool bit = act && ((h >> g) & 1u), own = act && to == g;
+          bool mem;
+          if (kind == 0) mem = bit && ds_ld(&firstg[(size_t)r * P + g]) == i;
+          else if (kind == 1) mem = own && bit;
+          else if (kind == 2) mem = own;
+          else if (kind == 3) mem = own && (h & ~(1u << g)) != 0;
+          else mem = bit && !own;
+          if (kind != 0) {
+            // bipartite.h `back() == nd1`: the previous member entry of this list is the same id
+            uint32_t tot;
+            uint32_t pm = ds_block_scan<true>(mem ? i + 1 : 0u, s_w, tot);
+            if (pm < prev_run) pm = prev_run;
+            if (tot > prev_run) prev_run = tot;
+            if (mem && pm != 0 && rep[pm - 1] == r) mem = false;
+          }
+          uint32_t tot;
+          const uint32_t rank = run + ds_block_scan<false>(mem ? 1u : 0u, s_w, tot);
+          run += tot;
+          if (pass == 0) {
+            if (kind == 0 && mem) outidx[(size_t)i * P + g] = rank;
+          } else if (act) {
+            // index of the id in slice g's out_nodes (any occurrence may have pushed it), or -1
+            const uint32_t fo = ds_ld(&firstg[(size_t)r * P + g]);
+            const int oi = fo == UNSET ? -1 : (int)ds_ld(&outidx[(size_t)fo * P + g]);
+            if (kind == 1 && mem) ar[a.list_base[CSL_OWNED_OUT_NODES] + s_off[1][g] + rank] = oi;
+            if (kind == 2) {
+              if (mem) ar[a.list_base[CSL_SELF_IDS_OUT] + s_off[2][g] + rank] = oi;
+              if (own) selfpos[i] = mem ? s_off[2][g] + rank : UNSET;  // where k_selfin puts self_ids_in
+            }
+            if (kind == 3 && mem) ar[a.list_base[CSL_TO_IDS] + s_off[3][g] + rank] = oi;
+            if (kind == 4 && mem) ar[a.list_base[CSL_FROM_IDS] + s_off[4][g] + rank] = oi;
+          }
+        }
+        if (pass == 0 && n == 0) s_cnt[kind][g] = run;
+      }
+    }
+    __syncthreads();
+    if (pass == 0) {
+      if (n < 5) {
+        uint32_t run = 0;
+        for (uint32_t g = 0; g <= CSL_MAX_PARTS; g++) {
+          s_off[n][g] = run;
+          if (g < P) run += s_cnt[n][g];
+        }
+        const int list = n == 0 ? CSL_OUT_NODES : n == 1 ? CSL_OWNED_OUT_NODES : n == 2 ? CSL_SELF_IDS_OUT
+                       : n == 3 ? CSL_TO_IDS : CSL_FROM_IDS;
+        for (uint32_t g = 0; g <= CSL_MAX_PARTS; g++) {
+          m.off[list][g] = s_off[n][g];
+          if (n == 2) m.off[CSL_SELF_IDS_IN][g] = s_off[n][g];
+        }
+      }
+      __syncthreads();
+      // out_nodes themselves: the first occurrences, in frontier order (their ranks are known now)
+      for (uint32_t i = n; i < F; i += DS_T) {
+        const uint32_t v = fr[i], h = hbv[i], r = rep[i];
+        for (uint32_t g = 0; g < P; g++)
+          if (((h >> g) & 1u) && ds_ld(&firstg[(size_t)r * P + g]) == i)
+            ar[a.list_base[CSL_OUT_NODES] + s_off[0][g] + ds_ld(&outidx[(size_t)i * P + g])] = (int)v;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ---- k_graph (CSL_MODE_GRAPH only): what BiPartite::add_edge was meant to build
 // (bipartite.h:55-66) and what slice_layer meant to record per peer
 // (slicer.cpp:40-43): CSR row pointers and local source indices of every slice,
@@ -1494,6 +1662,7 @@ struct csl_engine {
   uint64_t snap_round[NSNAP] = {};
   bool snap_pending[NSNAP] = {};
   uint64_t rounds_submitted = 0;
+  uint64_t snap_next = 0;  // oldest round whose snapshot has not been applied yet
   // capacities
   size_t fcap[CSL_MAX_LAYERS + 1];  // frontier capacity entering layer l
   size_t fcap_max = 0, ccap_max = 0;
@@ -1509,6 +1678,12 @@ struct csl_engine {
   uint32_t* crank = nullptr;
   uint8_t* ecnt = nullptr;
   uint32_t* srcpos = nullptr;
+  uint32_t* dupflag = nullptr;   // [nsets][S]
+  uint32_t* seedrep = nullptr;   // [nsets][S][fcap0]
+  uint32_t* dupfirst = nullptr;  // [nsets][S][fcap0*P]
+  uint32_t* dupout = nullptr;
+  unsigned long long* rngend = nullptr;  // [nsets][S]
+  uint32_t* candk = nullptr;     // CSL_FLAG_KEEP_CANDIDATES: [slots][L][S][ccap_max]
   uint2* queue = nullptr;
   uint32_t* nbk = nullptr;
   uint32_t* bcnt = nullptr;
@@ -1623,28 +1798,52 @@ int refresh_positions(csl_engine* e) {
   HIPCHECK(hipMemcpy(tmp.data(), e->rngpos, sizeof(unsigned long long) * e->S, hipMemcpyDeviceToHost));
   for (int s = 0; s < e->S; s++) e->pos_ub[s] = e->pos_lb[s] = tmp[s];
   for (int k = 0; k < csl_engine::NSNAP; k++) e->snap_pending[k] = false;
+  e->snap_next = e->rounds_submitted;
   return 0;
 }
 
-// newest completed position snapshot -> tight bounds without a sync
-void poll_snapshots(csl_engine* e) {
-  int best = -1;
-  for (int k = 0; k < csl_engine::NSNAP; k++) {
-    if (!e->snap_pending[k]) continue;
-    if (hipEventQuery(e->snap_ev[k]) != hipSuccess) continue;
-    if (best < 0 || e->snap_round[k] > e->snap_round[best]) best = k;
-  }
-  if (best < 0) return;
-  const uint64_t after = e->rounds_submitted - (e->snap_round[best] + 1);  // rounds submitted since
-  const unsigned long long* sn = e->snap_host + (size_t)best * e->S;
+// Position snapshots are applied strictly in round order: round q's end positions become the streams' lower
+// bounds only when the snapshots of ALL rounds <= q have completed, i.e. when no round that may still read
+// ring words below them is in flight (rounds overlap on different HIP streams; later rounds only read at
+// or above round q's end positions).
+void apply_snapshot(csl_engine* e, int k) {
+  const uint64_t after = e->rounds_submitted - (e->snap_round[k] + 1);  // rounds submitted since
+  const unsigned long long* sn = e->snap_host + (size_t)k * e->S;
   for (int s = 0; s < e->S; s++) {
-    // a snapshot may mix two consecutive rounds' values: both are valid lower bounds
     if (sn[s] > e->pos_lb[s]) e->pos_lb[s] = sn[s];
     const uint64_t ub = sn[s] + after * e->worst_draws;
     if (ub < e->pos_ub[s] && ub >= e->pos_lb[s]) e->pos_ub[s] = ub;
   }
-  for (int k = 0; k < csl_engine::NSNAP; k++)
-    if (e->snap_pending[k] && e->snap_round[k] <= e->snap_round[best]) e->snap_pending[k] = false;
+  e->snap_pending[k] = false;
+  e->snap_next = e->snap_round[k] + 1;
+}
+int snap_slot_of(csl_engine* e, uint64_t round) {
+  const int k = (int)(round % csl_engine::NSNAP);
+  return (e->snap_pending[k] && e->snap_round[k] == round) ? k : -1;
+}
+void poll_snapshots(csl_engine* e) {
+  while (e->snap_next < e->rounds_submitted) {
+    const int k = snap_slot_of(e, e->snap_next);
+    if (k < 0) {  // (dropped by refresh_positions)
+      e->snap_next++;
+      continue;
+    }
+    if (hipEventQuery(e->snap_ev[k]) != hipSuccess) break;
+    apply_snapshot(e, k);
+  }
+}
+// blocking form: everything up to and including `round` (a snapshot buffer is about to be reused)
+int retire_snapshots(csl_engine* e, uint64_t round) {
+  while (e->snap_next <= round) {
+    const int k = snap_slot_of(e, e->snap_next);
+    if (k < 0) {
+      e->snap_next++;
+      continue;
+    }
+    HIPCHECK(hipEventSynchronize(e->snap_ev[k]));
+    apply_snapshot(e, k);
+  }
+  return 0;
 }
 
 hipEvent_t rng_get_event(csl_engine* e) {
@@ -1757,7 +1956,8 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     Timed t(e, KN_SEEDS, st);
     dim3 grid((unsigned)((e->fcap[0] + TN - 1) / TN), S);
     hipLaunchKernelGGL(k_seeds, grid, dim3(TN), 0, st, nodes_dev, dd,
-                       e->fr[0] + (size_t)slot * S * e->fcap[0], e->fcap[0], fsize, meta, e->N, L);
+                       e->fr[0] + (size_t)slot * S * e->fcap[0], e->fcap[0], fsize, meta, e->N, L,
+                       e->dupflag + (size_t)set * S);
   }
   for (int l = 0; l < L; l++) {
     LArgs a;
@@ -1811,6 +2011,13 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.graph = e->cfg.mode == CSL_MODE_GRAPH ? 1u : 0u;
     a.ecnt = e->ecnt ? e->ecnt + sF * e->P : nullptr;
     a.srcpos = e->srcpos ? e->srcpos + sC : nullptr;
+    a.dupflag = e->dupflag + (size_t)set * S;
+    a.fcap0 = e->fcap[0];
+    a.seedrep = e->seedrep + (size_t)set * S * e->fcap[0];
+    a.dupfirst = e->dupfirst ? e->dupfirst + (size_t)set * S * e->fcap[0] * e->P : nullptr;
+    a.dupout = e->dupout ? e->dupout + (size_t)set * S * e->fcap[0] * e->P : nullptr;
+    a.rngend = e->rngend + (size_t)set * S;
+    a.candk = e->candk ? e->candk + ((size_t)slot * L + l) * S * e->ccap_max : nullptr;
     const dim3 blk(TN);
     const unsigned tiles_in = (unsigned)((e->fcap[l] + TN - 1) / TN);
     const size_t ccap_l = (size_t)tiles_in * TN * a.W;
@@ -1841,17 +2048,26 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
         HIPCHECK(hipEventRecord(e->chain_event, st));
         e->chain_valid = true;
       }
-      const int k = (int)(e->rounds_submitted % csl_engine::NSNAP);
-      if (e->snap_pending[k]) HIPCHECK(hipEventSynchronize(e->snap_ev[k]));
-      HIPCHECK(hipMemcpyAsync(e->snap_host + (size_t)k * S, e->rngpos, sizeof(unsigned long long) * S,
-                              hipMemcpyDeviceToHost, st));
-      HIPCHECK(hipEventRecord(e->snap_ev[k], st));
-      e->snap_round[k] = e->rounds_submitted;
-      e->snap_pending[k] = true;
     }
     {
       Timed t(e, KN_SAMPLE, st);
       hipLaunchKernelGGL(k_sample, grid_sample, blk, lds_hist, st, a);
+    }
+    if (l == L - 1) {
+      // Snapshot of the streams' positions AFTER this round (tightens the host's bounds without a sync).
+      // It is taken from the scratch set's own copy and only after the round's last k_sample: once the
+      // snapshot's event has completed, nothing of this round reads the ring any more, so -- applied in
+      // round order (poll_snapshots) -- these positions are the floor below which the generator may recycle.
+      const int k = (int)(e->rounds_submitted % csl_engine::NSNAP);
+      if (e->snap_pending[k]) {
+        int r2 = retire_snapshots(e, e->snap_round[k]);
+        if (r2) return r2;
+      }
+      HIPCHECK(hipMemcpyAsync(e->snap_host + (size_t)k * S, a.rngend, sizeof(unsigned long long) * S,
+                              hipMemcpyDeviceToHost, st));
+      HIPCHECK(hipEventRecord(e->snap_ev[k], st));
+      e->snap_round[k] = e->rounds_submitted;
+      e->snap_pending[k] = true;
     }
     {
       Timed t(e, KN_SCAN_Q, st);
@@ -1881,6 +2097,10 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     if (a.graph) {
       Timed t(e, KN_EDGES, st);
       hipLaunchKernelGGL(k_graph, grid_in, blk, 0, st, a);
+    } else if (l == 0) {
+      // repeated seed ids (bipartite.cpp:3-17): returns at once for a stream whose seeds are distinct
+      Timed t(e, KN_DUPSEEDS, st);
+      hipLaunchKernelGGL(k_dupseeds, dim3(S), dim3(DS_T), 0, st, a);
     }
     {
       Timed t(e, KN_SELFIN, st);
@@ -1919,7 +2139,8 @@ void csl_destroy(csl_engine* e) {
   void* ptrs[] = {e->rowinfo, e->off32, e->indices, e->wl,      e->nodes, e->seedbuf, e->ring,  e->mt_state, e->rngpos,
                   e->rngbase, e->ninfo,   e->hasedge, e->selfpos, e->firstpos, e->cand, e->cflag, e->crank,
                   e->queue,   e->nbk,     e->bcnt,    e->bcur,    e->tcnt,     e->fsize, e->meta, e->desc_dev,
-                  e->ecnt,    e->srcpos,  e->acc};
+                  e->ecnt,    e->srcpos,  e->acc,     e->dupflag, e->seedrep, e->dupfirst, e->dupout, e->rngend,
+                  e->candk};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (int l = 0; l <= CSL_MAX_LAYERS; l++)
@@ -2031,6 +2252,15 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
     DMALLOC(e->srcpos, e->nsets * (size_t)S * e->ccap_max);
   }
   DMALLOC(e->queue, e->nsets * (size_t)S * e->ccap_max);
+  DMALLOC(e->dupflag, e->nsets * (size_t)S);
+  DMALLOC(e->seedrep, e->nsets * (size_t)S * e->fcap[0]);
+  if (cfg->mode == CSL_MODE_STRICT) {
+    DMALLOC(e->dupfirst, e->nsets * (size_t)S * e->fcap[0] * P);
+    DMALLOC(e->dupout, e->nsets * (size_t)S * e->fcap[0] * P);
+  }
+  DMALLOC(e->rngend, e->nsets * (size_t)S);
+  HIPCHECK(hipMemsetAsync(e->rngend, 0, sizeof(unsigned long long) * e->nsets * S, e->stream));
+  if (cfg->flags & CSL_FLAG_KEEP_CANDIDATES) DMALLOC(e->candk, (size_t)e->slots * L * S * e->ccap_max);
   e->nbmax = (uint32_t)((e->ccap_max + QMEAN - 1) / QMEAN);
   if (e->nbmax < 1) e->nbmax = 1;
   if (e->nbmax > 8192)
@@ -2133,10 +2363,12 @@ int csl_create(const csl_config* cfg, csl_engine** out) {
   if (cfg->max_batch < 1) return fail(CSL_E_INVALID, "max_batch must be >= 1");
   if (cfg->mode != CSL_MODE_STRICT && cfg->mode != CSL_MODE_GRAPH) return fail(CSL_E_INVALID, "unknown mode %d", cfg->mode);
   if (!cfg->indptr || (!cfg->indices && cfg->num_edges > 0)) return fail(CSL_E_INVALID, "graph arrays missing");
-  // the reference keeps ids and row offsets in `int` (slicer.cpp:9,16;
-  // bipartite.h:55): bit-exact behaviour is only defined below 2^31
+  // the reference keeps ids in `int` (bipartite.h:55): node ids are only defined below 2^31.  Row offsets:
+  // the reference's `int offset` (slicer.cpp:9) wraps at 2^31 edges, i.e. its behaviour is undefined beyond;
+  // here offsets are 64-bit up to the 40 bits the packed row table holds (u32 offsets below 2^32 edges,
+  // (offset << 24 | degree) above), so graphs the reference cannot index still slice as it meant to.
   if (cfg->num_nodes < 1 || cfg->num_nodes >= (1ll << 31)) return fail(CSL_E_INVALID, "num_nodes must be in [1, 2^31)");
-  if (cfg->num_edges < 0 || cfg->num_edges >= (1ll << 31)) return fail(CSL_E_INVALID, "num_edges must be in [0, 2^31)");
+  if (cfg->num_edges < 0 || cfg->num_edges >= (1ll << 40)) return fail(CSL_E_INVALID, "num_edges must be in [0, 2^40)");
   for (int l = 0; l < cfg->n_layers; l++)
     if (cfg->fanout[l] < 1 || cfg->fanout[l] > 255) return fail(CSL_E_INVALID, "fanout[%d] must be 1..255", l);
   if (cfg->indptr[0] != 0 || cfg->indptr[cfg->num_nodes] != cfg->num_edges)
@@ -2432,6 +2664,39 @@ int64_t csl_copy_frontier(csl_engine* e, int32_t slot, int32_t stream, int32_t l
   }
   for (int64_t i = 0; i < n; i++) dst[i] = (int64_t)tmp[(size_t)i];
   return n;
+}
+
+int64_t csl_copy_candidates(csl_engine* e, int32_t slot, int32_t stream, int32_t layer, int64_t* flat, int64_t cap_flat,
+                            int64_t* counts, int64_t cap_counts) {
+  if (!e || !flat || !counts) return fail(CSL_E_INVALID, "null argument");
+  if (!e->candk) return fail(CSL_E_STATE, "engine was not created with CSL_FLAG_KEEP_CANDIDATES");
+  if (slot < 0 || slot >= e->slots || stream < 0 || stream >= e->S || layer < 0 || layer >= e->L)
+    return fail(CSL_E_INVALID, "index out of range");
+  hipSetDevice(e->cfg.device);
+  int r = load_meta(e, slot);
+  if (r) return r;
+  const csl_sample_meta& sm = e->meta_host[(size_t)slot * e->S + stream];
+  const size_t F = sm.layer[layer].frontier, W = (size_t)e->cfg.fanout[layer] + 1;
+  if ((int64_t)F > cap_counts) return fail(CSL_E_INVALID, "counts too small: need %zu", F);
+  std::vector<uint32_t> tmp(F * W);
+  if (F) {
+    const uint32_t* src = e->candk + (((size_t)slot * e->L + layer) * e->S + stream) * e->ccap_max;
+    hipError_t er = hipMemcpy(tmp.data(), src, sizeof(uint32_t) * F * W, hipMemcpyDeviceToHost);
+    if (er != hipSuccess) return fail(CSL_E_HIP, "hipMemcpy failed: %s", hipGetErrorString(er));
+  }
+  int64_t o = 0;
+  for (size_t i = 0; i < F; i++) {
+    int64_t c = 0;
+    for (size_t j = 0; j < W; j++) {
+      const uint32_t v = tmp[i * W + j];
+      if (v == UNSET) continue;  // a row shorter than the fanout: slots past its degree
+      if (o >= cap_flat) return fail(CSL_E_INVALID, "flat too small");
+      flat[o++] = (int64_t)v;
+      c++;
+    }
+    counts[i] = c;
+  }
+  return o;
 }
 
 int csl_hip_stream(csl_engine* e, int32_t slot, void** out) {

@@ -89,7 +89,7 @@ def test_degenerate_graphs(abi, orc):
     for indptr, indices, batches, fan, P in cases:
         indptr = np.asarray(indptr, dtype=np.int64)
         indices = np.asarray(indices, dtype=np.int64)
-        e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=8)
+        e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=8, flags=abi.FLAG_KEEP_CANDIDATES)
         eg = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=8, mode=abi.MODE_GRAPH)
         o, og = orc.Oracle(indptr, indices, n_parts=P, fanouts=fan), orc.Oracle(indptr, indices, n_parts=P, fanouts=fan)
         for b in batches:
@@ -143,7 +143,7 @@ def test_randomised_configurations(abi, orc, seed):
     perm = rng.permutation(n)
     mode_graph = bool(rng.random() < 0.4)
     e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2, workload=wl,
-                   mode=abi.MODE_GRAPH if mode_graph else abi.MODE_STRICT)
+                   mode=abi.MODE_GRAPH if mode_graph else abi.MODE_STRICT, flags=abi.FLAG_KEEP_CANDIDATES)
     e.set_nodes(perm)
     oracles = [orc.Oracle(indptr, indices, n_parts=P, fanouts=fan, workload=wl) for _ in range(S)]
     nb = (n + B - 1) // B
@@ -195,7 +195,8 @@ def test_extreme_parameters(abi, orc):
     indptr, indices = l0.synth_graph(3000, 300.0, seed=23)
     perm = np.random.default_rng(4).permutation(3000)
     # fanout 255, 2 layers
-    e = abi.Engine(indptr, indices, n_parts=7, fanouts=(255, 2), max_batch=5, n_streams=2)
+    e = abi.Engine(indptr, indices, n_parts=7, fanouts=(255, 2), max_batch=5, n_streams=2,
+                   flags=abi.FLAG_KEEP_CANDIDATES)
     e.submit_seeds([perm[:5], perm[5:6]])
     for s, seeds in enumerate([perm[:5], perm[5:6]]):
         assert_same_sample(e.sample_dict(s), orc.Oracle(indptr, indices, n_parts=7, fanouts=(255, 2)).sample(seeds),
@@ -204,14 +205,16 @@ def test_extreme_parameters(abi, orc):
     # four layers
     indptr, indices = l0.synth_graph(20000, 8.0, seed=24)
     perm = np.random.default_rng(5).permutation(20000)
-    e = abi.Engine(indptr, indices, n_parts=3, fanouts=(4, 3, 3, 2), max_batch=50, n_streams=1)
+    e = abi.Engine(indptr, indices, n_parts=3, fanouts=(4, 3, 3, 2), max_batch=50, n_streams=1,
+                   flags=abi.FLAG_KEEP_CANDIDATES)
     e.submit_seeds([perm[:50]])
     assert_same_sample(e.sample_dict(0), orc.Oracle(indptr, indices, n_parts=3, fanouts=(4, 3, 3, 2)).sample(perm[:50]),
                        what="four layers")
     e.close()
     # many streams, tiny minibatches
     S = 300
-    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(5, 5), max_batch=4, n_streams=S, n_slots=2)
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(5, 5), max_batch=4, n_streams=S, n_slots=2,
+                   flags=abi.FLAG_KEEP_CANDIDATES)
     e.set_nodes(perm)
     e.submit_round(0, 4, S)
     for s in (0, 1, 137, 299):
@@ -228,7 +231,8 @@ def test_full_tile_at_max_fanout(abi, orc):
     indptr, indices = l0.synth_graph(2000, 300.0, seed=31)
     perm = np.random.default_rng(6).permutation(2000)
     for mode in (abi.MODE_STRICT, abi.MODE_GRAPH):
-        e = abi.Engine(indptr, indices, n_parts=2, fanouts=(255,), max_batch=300, n_streams=1, mode=mode)
+        e = abi.Engine(indptr, indices, n_parts=2, fanouts=(255,), max_batch=300, n_streams=1, mode=mode,
+                       flags=abi.FLAG_KEEP_CANDIDATES)
         e.submit_seeds([perm[:300]])
         o = orc.Oracle(indptr, indices, n_parts=2, fanouts=(255,))
         if mode == abi.MODE_STRICT:
@@ -246,7 +250,8 @@ def test_frontier_longer_than_the_register_scan(abi, orc):
     n = 320_000
     indptr, indices = l0.synth_graph(n, 30.0, seed=33)
     perm = np.random.default_rng(7).permutation(n)
-    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(20, 20, 2), max_batch=4096, n_streams=1)
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(20, 20, 2), max_batch=4096, n_streams=1,
+                   flags=abi.FLAG_KEEP_CANDIDATES)
     e.submit_seeds([perm[:4096]])
     got = e.sample_dict(0)
     assert max(len(f) for f in got["frontier"]) > 64 * 12 * 256, [len(f) for f in got["frontier"]]
@@ -267,7 +272,8 @@ def test_both_row_lookup_tables(abi, orc, monkeypatch):
             monkeypatch.setenv("CSLICER_ROWINFO64", "1")
         else:
             monkeypatch.delenv("CSLICER_ROWINFO64", raising=False)
-        e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 5, 5), max_batch=200, n_streams=1)
+        e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 5, 5), max_batch=200, n_streams=1,
+                       flags=abi.FLAG_KEEP_CANDIDATES)
         e.submit_seeds([perm[:200]])
         assert_same_sample(e.sample_dict(0), want, what="row lookup table, 64-bit=%s" % force64)
         e.close()
