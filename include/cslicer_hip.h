@@ -140,6 +140,10 @@ typedef struct {
   /* graph mode: pair_off[0][g][p] = start of (g -> p) inside slice g's from_ids
    * segment, pair_off[1][p][g] = start of (g -> p) inside slice p's to_ids segment */
   uint32_t pair_off[2][CSL_MAX_PARTS][CSL_MAX_PARTS + 1];
+  /* strict mode: length of slice g's exported `indptr`: one `1` per out_nodes PUSH (bipartite.h:59-62), which
+   * reorder() does not deduplicate.  Equals len(out_nodes) unless the minibatch repeats a seed id (layer 0).
+   * graph mode: len(out_nodes) + 1 when the layer is not empty (the CSR row pointers). */
+  uint32_t indptr_len[CSL_MAX_PARTS];
 } csl_layer_meta;
 
 typedef struct {

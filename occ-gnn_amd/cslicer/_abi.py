@@ -69,6 +69,7 @@ class LayerMeta(C.Structure):
         ("sampled_edges", C.c_uint32),
         ("off", (C.c_uint32 * (MAX_PARTS + 1)) * NUM_LISTS),
         ("pair_off", ((C.c_uint32 * (MAX_PARTS + 1)) * MAX_PARTS) * 2),
+        ("indptr_len", C.c_uint32 * MAX_PARTS),
     ]
 
 
@@ -307,8 +308,8 @@ class Engine:
                     "indices": np.zeros(0, dtype=np.int64),
                     "gpu_id": g,
                 }
-                # bipartite.h:55-66: one `1` per out_nodes push, CSR never built
-                bp["indptr"] = np.ones(bp["out_nodes"].shape[0], dtype=np.int64)
+                # bipartite.h:55-66: one `1` per out_nodes push (not deduplicated by reorder), CSR never built
+                bp["indptr"] = np.ones(int(m.layer[l].indptr_len[g]), dtype=np.int64)
                 empty = np.zeros(0, dtype=np.int64)
                 bp["from_ids"] = [get(FROM_IDS) if j == g else empty for j in range(self.n_parts)]
                 bp["to_ids"] = [get(TO_IDS) if j == g else empty for j in range(self.n_parts)]

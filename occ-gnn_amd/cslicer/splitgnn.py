@@ -28,7 +28,7 @@ that do not leave the GPU).
 import torch
 import torch.nn as nn
 
-from . import _abi, aggr
+from . import _abi, _roctx, aggr
 
 
 class _DevArray(object):
@@ -559,6 +559,10 @@ class DistComm(object):
         return self._side
 
     def _exchange(self, send_cat, send_counts, recv_counts):
+        with _roctx.range("exchange"):
+            return self._exchange_impl(send_cat, send_counts, recv_counts)
+
+    def _exchange_impl(self, send_cat, send_counts, recv_counts):
         H = send_cat.shape[1]
         if self.dist.get_backend(self.group) == "gloo" and send_cat.is_cuda:
             # rehearsal backend (several ranks sharing one GPU): stage through host memory

@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-from . import _abi, aggr, splitgnn
+from . import _abi, _roctx, aggr, splitgnn
 
 
 class Trainer(object):
@@ -60,15 +60,21 @@ class Trainer(object):
         self.n_batches = (len(nodes) + self.B - 1) // self.B
 
     def _step(self, stream, slot):
+        # ROCTX ranges = the reference's nvtx annotations (python/train.py:68, dist_sageconv.py:52-65)
         t0 = time.perf_counter()
+        _roctx.push("slice")
         meta = self.eng.meta(stream, slot)
         slices = splitgnn.slices_of(self.eng, stream, slot, parts=[self.rank], device=self.dev, meta=meta)
+        _roctx.pop()
         self.t_slice += time.perf_counter() - t0
         deep = slices[self.L - 1][self.rank]
         # gather of owned input features (row v // P of the owner v % P), int32 indices, float4 row kernel
+        _roctx.push("gather")
         rows = deep.in_nodes if self.P == 1 else torch.div(deep.in_nodes, self.P, rounding_mode="floor")
         x = aggr.gather_rows(self.feat, rows)
+        _roctx.pop()
         t1 = time.perf_counter()
+        _roctx.push("forward")
         if self.rank_path:
             if self.kind == "gat":
                 logits = self.model.forward_rank(slices, x, self.rank, self.comm)
@@ -82,10 +88,14 @@ class Trainer(object):
         # mean over the WHOLE minibatch: sum of local losses / global seed count
         n_seeds = int(meta.n_seeds)
         loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / max(n_seeds, 1)
+        _roctx.pop()
         self.t_forward += time.perf_counter() - t1
+        _roctx.push("backward")
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
+        _roctx.pop()
         if self.rank_path:
+            _roctx.push("grad_allreduce")
             # (a rank whose share of the minibatch produced no gradient for a parameter still takes part)
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                               for p in self.model.parameters()])
@@ -98,7 +108,10 @@ class Trainer(object):
                 else:
                     p.grad.copy_(flat[o:o + n].view_as(p))
                 o += n
+            _roctx.pop()
+        _roctx.push("optimizer")
         self.opt.step()
+        _roctx.pop()
         self.steps_done += 1
         return loss.detach()
 

@@ -434,6 +434,8 @@ __global__ __launch_bounds__(PHASE == 0 ? TN : SCAN_T) void k_scan(LArgs a) {
         }
         for (int g = P; g <= CSL_MAX_PARTS; g++) m.off[kind][g] = run;
       }
+      for (int g = 0; g < CSL_MAX_PARTS; g++)
+        m.indptr_len[g] = g < P ? (a.graph ? tot[CSL_INDPTR][g] : tot[CSL_OUT_NODES][g]) : 0u;
     }
   }
 }
@@ -1275,7 +1277,7 @@ __global__ __launch_bounds__(DS_T) void k_dupseeds(LArgs a) {
   int* ar = a.arena + (size_t)s * a.arena_stride;
   csl_layer_meta& m = a.meta[s].layer[0];
   __shared__ uint32_t s_w[DS_T / 64];
-  __shared__ uint32_t s_cnt[5][CSL_MAX_PARTS];  // kinds OUT, OWNED, SELF, TO, FROM
+  __shared__ uint32_t s_cnt[6][CSL_MAX_PARTS];  // kinds OUT, OWNED, SELF, TO, FROM, out_nodes pushes (= indptr ones)
   __shared__ uint32_t s_off[5][CSL_MAX_PARTS + 1];
   for (uint32_t k = n; k < F * P; k += DS_T) firstg[k] = UNSET;
   __syncthreads();
@@ -1289,7 +1291,7 @@ __global__ __launch_bounds__(DS_T) void k_dupseeds(LArgs a) {
   // pass 0: out_nodes indices and the size of every list; pass 1: the lists
   for (int pass = 0; pass < 2; pass++) {
     for (uint32_t g = 0; g < P; g++) {
-      for (int kind = pass == 0 ? 0 : 1; kind < 5; kind++) {
+      for (int kind = pass == 0 ? 0 : 1; kind < (pass == 0 ? 6 : 5); kind++) {
         uint32_t run = 0, prev_run = 0;  // carried over the chunks: members so far, last member entry + 1
         for (uint32_t ch = 0; ch < chunks; ch++) {
           const uint32_t i = ch * DS_T + n;
@@ -1307,7 +1309,8 @@ __global__ __launch_bounds__(DS_T) void k_dupseeds(LArgs a) {
           else if (kind == 1) mem = own && bit;
           else if (kind == 2) mem = own;
           else if (kind == 3) mem = own && (h & ~(1u << g)) != 0;
-          else mem = bit && !own;
+          else if (kind == 4) mem = bit && !own;
+          else mem = bit;  // out_nodes pushes before reorder (bipartite.h:59-62): each leaves a `1` in indptr
           if (kind != 0) {
             // bipartite.h `back() == nd1`: the previous member entry of this list is the same id
             uint32_t tot;
@@ -1352,6 +1355,7 @@ __global__ __launch_bounds__(DS_T) void k_dupseeds(LArgs a) {
           if (n == 2) m.off[CSL_SELF_IDS_IN][g] = s_off[n][g];
         }
       }
+      if (n >= 64 && n < 64 + P) m.indptr_len[n - 64] = s_cnt[5][n - 64];
       __syncthreads();
       // out_nodes themselves: the first occurrences, in frontier order (their ranks are known now)
       for (uint32_t i = n; i < F; i += DS_T) {

@@ -357,7 +357,7 @@ class CSlicer {
       take(l, CSL_SELF_IDS_OUT, g, b->self_ids_out);
       take(l, CSL_TO_IDS, g, b->to_ids[g]);      // own index only, slicer.cpp:41
       take(l, CSL_FROM_IDS, g, b->from_ids[g]);  // slicer.cpp:42
-      b->indptr.assign(b->out_nodes.size(), 1);  // bipartite.h:55-66: one `1` per push, CSR never built
+      b->indptr.assign((size_t)m.layer[l].indptr_len[g], 1);  // bipartite.h:55-66: one `1` per push, CSR never built
     };
     // deepest layer first: its bipartites are the big tasks
     const std::function<void(int)> rev = [&](int t) { one(n_layers_ * n_parts_ - 1 - t); };

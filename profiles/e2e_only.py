@@ -15,7 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "occ-gnn_amd"))
-from cslicer import l0  # noqa: E402
+from cslicer import _roctx, l0  # noqa: E402
 from cslicer.train import Trainer, synthetic_node_data  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -48,8 +48,10 @@ t.set_nodes(np.random.default_rng(1).permutation(n))
 t.run(a.warmup)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
+_roctx.push("timed_region")      # profiles/e2e_summarize.py windows the kernel trace with this range
 t.run(a.steps, first_batch=a.warmup)
 torch.cuda.synchronize()
+_roctx.pop()
 dt = time.perf_counter() - t0
 print(json.dumps({"e2e_only": True, "model": a.model, "steps": a.steps, "ms_per_step": 1e3 * dt / a.steps,
                   "iters_per_sec": a.steps / dt}))

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Condenses a rocprofv3 --kernel-trace --stats run of profiles/e2e_only.py into a markdown table:
 per-kernel share of the GPU time, grouped (library GEMMs / aggregation kernels of libcslicer_hip /
-slicer kernels / torch elementwise+optimizer), and the GPU-busy fraction of the steady-state window
-(union of kernel intervals / window; the window is the last 60 % of the trace's time span).
+slicer kernels / torch elementwise+optimizer), and the GPU-busy fraction of the timed region
+(union of kernel intervals / window; the window is the ROCTX range `timed_region` of e2e_only.py,
+from `--marker-trace`).
 
-usage: python3 profiles/e2e_summarize.py <rocprof dir> <steps incl. warmup> > summary.md"""
+usage: python3 profiles/e2e_summarize.py <rocprof dir> <timed steps> > summary.md"""
 import csv
 import glob
 import os
@@ -30,8 +31,16 @@ def main():
     trace = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(trace)))
     iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-    t0, t1 = iv[0][0], max(e for _, e, _ in iv)
-    w0 = t0 + int(0.4 * (t1 - t0))
+    mk = glob.glob(os.path.join(d, "**", "*marker_api_trace.csv"), recursive=True)
+    w0 = w1 = None
+    if mk:
+        for r in csv.DictReader(open(mk[0])):
+            if "timed_region" in (r.get("Function", "") + r.get("Message", "")):
+                w0, w1 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    if w0 is None:
+        raise SystemExit("no `timed_region` marker in the trace (run rocprofv3 with --marker-trace)")
+    iv = [(s_, min(e_, w1), n_) for s_, e_, n_ in iv if s_ < w1]
+    t1 = w1
     busy, cur_s, cur_e = 0, None, None
     per, cnt = {}, {}
     for s, e, n in iv:
@@ -50,8 +59,8 @@ def main():
         busy += cur_e - cur_s
     window = t1 - w0
     tot = sum(per.values())
-    steps_w = steps * 0.6
-    print("# e2e training step: rocprofv3 kernel trace, steady-state window (last 60 %% of the run)\n")
+    steps_w = steps
+    print("# e2e training step: rocprofv3 kernel trace of the timed region (%d steps)\n" % steps)
     print("window %.1f ms, GPU busy (union of kernel intervals) %.1f ms = **%.1f %%**; sum of kernel durations "
           "%.1f ms (overlap of the slicer's side streams with the step: %.2fx); ~%.3f ms of kernel time per step\n"
           % (window / 1e6, busy / 1e6, 100.0 * busy / window, tot / 1e6, tot / max(busy, 1), tot / 1e6 / steps_w))
