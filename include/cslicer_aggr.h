@@ -65,6 +65,41 @@ int csl_gat_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_row
                     const float* z, int32_t H, int32_t D, float slope, const float* m_in, const float* g_s,
                     const float* g_n, float* g_el, float* g_er, float* g_z, void* stream);
 
+
+/* ---- fused GraphSAGE layer pieces (DistSageConv.forward, python/layers/dist_sageconv.py:42-84) ----
+ *
+ * csl_sage_cat_f32: the operand of Linear(2*in, out) in one pass (self_gather + gather/mean + concat,
+ * dist_sageconv.py:66-80; python/data/bipartite.py:61-91):
+ *   cat[r, 0:H)  = act(x[map(self_ids[r])])                                   (zero row for self_ids[r] = -1)
+ *   cat[r, H:2H) = sum_{e in CSR row r} act(x[map(indices[e])]) / max(deg_r, 1)     when indptr != NULL
+ *                = agg[owned[r]] / max(deg[r], 1)                                   when indptr == NULL
+ * deg_r = deg ? deg[r] : (indptr[r+1] - indptr[r]); map(i) = rowmap ? rowmap[i] : i (the deepest layer reads the
+ * resident feature table through the slice's in_nodes); act = ReLU if relu_in (x is then the previous layer's
+ * pre-activation output).  Rows [n, n_pad) of cat are zeroed.  H % 4 == 0; x, agg, cat 16-byte aligned with
+ * leading dimensions that are multiples of 4. */
+int csl_sage_cat_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* owned,
+                     const int32_t* deg, const int32_t* rowmap, const float* x, int64_t ldx, const float* agg,
+                     int64_t lda, int64_t n, int64_t n_pad, float* cat, int64_t ldc, int32_t H, int32_t relu_in,
+                     void* stream);
+
+/* gradient of the CSR form above w.r.t. x: gx [n_src, ldx] is ZEROED here, then
+ *   gx[self_ids[r]] += gcat[r, 0:H),  gx[indices[e]] += gcat[r, H:2H) / max(indptr[r+1]-indptr[r], 1)  (fp32 atomics).
+ * (With relu_in the caller applies the ReLU mask of the layer below to gx: csl_relu_bwd_colsum_f32.) */
+int csl_sage_cat_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, int64_t n,
+                         const float* gcat, int64_t ldg, float* gx, int64_t ldx, int64_t n_src, int32_t H,
+                         void* stream);
+
+/* out[r, :] = (y == NULL || y[r, :] > 0) ? g[r, :] : 0 for r < n, zero rows for n <= r < n_pad;
+ * colsum[c] = sum_r out[r, c] (zeroed here first): ReLU backward + row padding of the GEMM operand + bias gradient. */
+int csl_relu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t n, int64_t n_pad,
+                            float* out, int64_t ldo, float* colsum, int32_t H, void* stream);
+
+/* cross-entropy (python/train.py:86), forward and backward in one pass: *loss (zeroed here first) =
+ * -scale * sum_r log softmax(logits[r])[label_r]; grad[r, :] = scale * (softmax(logits[r]) - onehot(label_r));
+ * label_r = labels[rowmap ? rowmap[ids[r]] : ids[r]] (int64 labels, int32 node ids). */
+int csl_softmax_ce_f32(const float* logits, int64_t ldl, int64_t n, int32_t C, const int32_t* ids, const int32_t* rowmap,
+                       const int64_t* labels, float scale, float* loss, float* grad, int64_t ldgr, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

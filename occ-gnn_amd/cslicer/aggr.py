@@ -12,7 +12,8 @@ import torch
 from . import _abi
 
 SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
-           "csl_scatter_add_rows_f32", "csl_div_rows_f32", "csl_gat_fwd_f32", "csl_gat_bwd_f32"]
+           "csl_scatter_add_rows_f32", "csl_div_rows_f32", "csl_gat_fwd_f32", "csl_gat_bwd_f32",
+           "csl_sage_cat_f32", "csl_sage_cat_bwd_f32", "csl_relu_bwd_colsum_f32", "csl_softmax_ce_f32"]
 _ready = False
 
 
@@ -29,6 +30,10 @@ def _lib():
         f32 = C.c_float
         L.csl_gat_fwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
         L.csl_gat_bwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
+        L.csl_sage_cat_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, vp, i64, i32, i32, vp]
+        L.csl_sage_cat_bwd_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, i64, i32, vp]
+        L.csl_relu_bwd_colsum_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, i64, vp, i32, vp]
+        L.csl_softmax_ce_f32.argtypes = [vp, i64, i64, i32, vp, vp, vp, f32, vp, vp, i64, vp]
         _ready = True
     return L
 
@@ -126,6 +131,75 @@ def div_rows_(x, deg):
     _chk(_lib().csl_div_rows_f32(_p(x), x.stride(0), _p(_i32(deg)), x.shape[0], x.shape[1], _stream()),
          "csl_div_rows_f32")
     return x
+
+
+def sage_cat(x, self_ids, n, n_pad, indptr=None, indices=None, owned=None, deg=None, agg=None, rowmap=None,
+             relu_in=False):
+    """The operand of Linear(2*in, out) in one pass (csl_sage_cat_f32): [n_pad, 2*H] with
+    cat[:, :H] = x[map(self_ids)], cat[:, H:] = mean over the CSR row of x[map(indices)] (indptr given) or
+    agg[owned] / deg (indptr None).  Rows n..n_pad are zero."""
+    x = _f32(x)
+    H = x.shape[1]
+    cat = torch.empty((n_pad, 2 * H), dtype=torch.float32, device=x.device)
+    nul = C.c_void_p(0)
+    if indptr is not None:
+        args = (_p(_i32(indptr)), _p(_i32(indices)), _p(_i32(self_ids)), nul, _p(deg) if deg is not None else nul,
+                _p(rowmap) if rowmap is not None else nul, _p(x), x.stride(0), nul, 0)
+    else:
+        agg = _f32(agg)
+        args = (nul, nul, _p(_i32(self_ids)), _p(_i32(owned)), _p(_i32(deg)),
+                _p(rowmap) if rowmap is not None else nul, _p(x), x.stride(0), _p(agg), agg.stride(0))
+    _chk(_lib().csl_sage_cat_f32(*args, n, n_pad, _p(cat), cat.stride(0), H, 1 if relu_in else 0, _stream()),
+         "csl_sage_cat_f32")
+    return cat
+
+
+def sage_cat_bwd(indptr, indices, self_ids, gcat, n, n_src):
+    """Gradient of sage_cat's CSR form w.r.t. x: a fresh [n_src, H] (zeroed inside the call, fp32 atomics)."""
+    gcat = _f32(gcat)
+    H = gcat.shape[1] // 2
+    gx = torch.empty((n_src, H), dtype=torch.float32, device=gcat.device)
+    _chk(_lib().csl_sage_cat_bwd_f32(_p(_i32(indptr)), _p(_i32(indices)), _p(_i32(self_ids)), n, _p(gcat),
+                                     gcat.stride(0), _p(gx), gx.stride(0), n_src, H, _stream()),
+         "csl_sage_cat_bwd_f32")
+    return gx
+
+
+def relu_bwd_colsum(g, y, n, n_pad):
+    """(out [n_pad, H], colsum [H]): out[:n] = g masked by y > 0 (y None: unmasked), zero pad rows, column sums."""
+    g = _f32(g)
+    H = g.shape[1]
+    out = torch.empty((n_pad, H), dtype=torch.float32, device=g.device)
+    colsum = torch.empty((H,), dtype=torch.float32, device=g.device)
+    _chk(_lib().csl_relu_bwd_colsum_f32(_p(g), g.stride(0), _p(y) if y is not None else C.c_void_p(0),
+                                        y.stride(0) if y is not None else 0, n, n_pad, _p(out), out.stride(0),
+                                        _p(colsum), H, _stream()), "csl_relu_bwd_colsum_f32")
+    return out, colsum
+
+
+class SoftmaxCE(torch.autograd.Function):
+    """Cross-entropy summed over the rows and scaled (python/train.py:86), forward and backward in one HIP pass:
+    label of row r = labels[rowmap[ids[r]]] (rowmap None: labels[ids[r]]); returns the scalar loss."""
+
+    @staticmethod
+    def forward(ctx, logits, ids, labels, scale, rowmap=None):
+        logits = _f32(logits)
+        n, Cn = logits.shape
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        grad = torch.empty((n, Cn), dtype=torch.float32, device=logits.device)
+        if labels.dtype != torch.int64:
+            raise TypeError("labels must be int64")
+        _chk(_lib().csl_softmax_ce_f32(_p(logits), logits.stride(0), n, Cn, _p(_i32(ids)),
+                                       _p(rowmap) if rowmap is not None else C.c_void_p(0), _p(labels), float(scale),
+                                       C.c_void_p(loss.data_ptr()), _p(grad), grad.stride(0), _stream()),
+             "csl_softmax_ce_f32")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None
 
 
 class SpmmSum(torch.autograd.Function):

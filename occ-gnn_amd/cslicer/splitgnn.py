@@ -142,59 +142,90 @@ class _SplitKLinear(torch.autograd.Function):
 
 
 class _SageFinish(torch.autograd.Function):
-    """DistSageConv.finish (+ the ReLU after it) as ONE autograd node: gathers write straight into the two
-    column blocks of the (row-padded) GEMM operand, no concat / pad / slice copies, and the backward is four
-    HIP launches and three GEMMs instead of a chain of ~10 autograd nodes.  The training step on one MI355X is
-    bound by host-side op dispatch, not by the GPU, so fewer nodes is what counts."""
+    """DistSageConv.finish (+ the ReLU after it) as ONE autograd node: csl_sage_cat_f32 writes the self rows and
+    the degree-normalised merged sums straight into the two column blocks of the (row-padded) GEMM operand, the
+    GEMM carries bias and ReLU in its epilogue, and the backward is csl_relu_bwd_colsum_f32 (mask + padding + bias
+    gradient in one pass), three GEMMs and two row scatters instead of a chain of ~10 autograd nodes."""
 
     @staticmethod
-    def forward(ctx, x, agg, weight, bias, self_ids_in, owned, deg, relu, indptr=None, indices=None, n_out=0):
-        # agg is None: the whole layer of a single part (no boundary exchange): the CSR aggregation happens
-        # in here too, and the backward sends the neighbour gradient straight through the CSR
-        ctx.local = agg is None
-        if ctx.local:
-            agg = aggr.spmm_sum(indptr, indices, x, n_out)
-        m, fin = owned.numel(), x.shape[1]
-        mp = (m + ROW_PAD - 1) // ROW_PAD * ROW_PAD if m >= ROW_PAD else m
-        cat = torch.empty((mp, 2 * fin), dtype=torch.float32, device=x.device)
-        if mp != m:
-            cat[m:].zero_()
-        aggr.gather_rows(x, self_ids_in, out=cat[:m, :fin])
-        aggr.div_rows_(aggr.gather_rows(agg, owned, out=cat[:m, fin:]), deg)
-        y = torch.addmm(bias, cat, weight.t())
-        if relu:
-            y.relu_()
+    def forward(ctx, x, agg, weight, bias, self_ids_in, owned, deg, relu):
+        m = owned.numel()
+        mp = _pad_rows(m)
+        cat = aggr.sage_cat(x, self_ids_in, m, mp, owned=owned, deg=deg, agg=agg)
+        y = _linear_act(bias, cat, weight, relu)
         ctx.relu, ctx.m, ctx.n_x, ctx.n_agg = relu, m, x.shape[0], agg.shape[0]
-        ctx.save_for_backward(cat, weight, self_ids_in, owned, deg, y if relu else None,
-                              indptr if ctx.local else None, indices if ctx.local else None)
+        ctx.save_for_backward(cat, weight, self_ids_in, owned, deg, y if relu else None)
         return y[:m]
 
     @staticmethod
     def backward(ctx, gy):
-        cat, weight, self_ids_in, owned, deg, y, indptr, indices = ctx.saved_tensors
+        cat, weight, self_ids_in, owned, deg, y = ctx.saved_tensors
         m, mp, fin = ctx.m, cat.shape[0], cat.shape[1] // 2
-        if ctx.relu:
-            gy = torch.ops.aten.threshold_backward(gy, y[:m], 0.0)   # ReLU backward, one kernel
-        gyp = torch.nn.functional.pad(gy, (0, 0, 0, mp - m)) if mp != m else gy.contiguous()
-        if mp >= ROW_PAD and mp % SPLIT_K == 0:
-            gw = torch.bmm(gyp.view(SPLIT_K, mp // SPLIT_K, gyp.shape[1]).transpose(1, 2),
-                           cat.view(SPLIT_K, mp // SPLIT_K, cat.shape[1])).sum(0)
-        else:
-            gw = gyp.t() @ cat
-        gb = gyp.sum(0)
+        gyp, gb = aggr.relu_bwd_colsum(gy, y, m, mp)
+        gw = _weight_grad(gyp, cat)
         gx = gagg = None
-        if ctx.needs_input_grad[0] or (ctx.needs_input_grad[1] and not ctx.local):
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             gcat = gyp @ weight
             if ctx.needs_input_grad[0]:
                 gx = torch.zeros((ctx.n_x, fin), dtype=torch.float32, device=gy.device)
                 aggr.scatter_add_rows_(gx, self_ids_in, gcat[:m, :fin])
-                if ctx.local:  # neighbour gradient of the owned rows, through the CSR, into the same buffer
-                    aggr.spmm_sum_bwd(indptr, indices, aggr.div_rows_(gcat[:m, fin:], deg), ctx.n_x, rows=owned,
-                                      compact=True, out=gx)
-            if ctx.needs_input_grad[1] and not ctx.local:
+            if ctx.needs_input_grad[1]:
                 gagg = torch.zeros((ctx.n_agg, fin), dtype=torch.float32, device=gy.device)
                 aggr.scatter_add_rows_(gagg, owned, aggr.div_rows_(gcat[:m, fin:], deg))
-        return gx, gagg, gw, gb, None, None, None, None, None, None, None
+        return gx, gagg, gw, gb, None, None, None, None
+
+
+def _pad_rows(m):
+    return (m + ROW_PAD - 1) // ROW_PAD * ROW_PAD if m >= ROW_PAD else m
+
+
+def _weight_grad(gyp, cat):
+    """gy^T @ cat for a tall, row-padded pair: SPLIT_K batched slabs + a sum (see _SplitKLinear)."""
+    mp = gyp.shape[0]
+    if mp >= ROW_PAD and mp % SPLIT_K == 0:
+        return torch.bmm(gyp.view(SPLIT_K, mp // SPLIT_K, gyp.shape[1]).transpose(1, 2),
+                         cat.view(SPLIT_K, mp // SPLIT_K, cat.shape[1])).sum(0)
+    return gyp.t() @ cat
+
+
+def _linear_act(bias, cat, weight, relu):
+    """cat @ W^T + b, with the ReLU in the GEMM's epilogue where the library offers it."""
+    if relu and _FUSED_EPILOGUE:
+        return torch._addmm_activation(bias, cat, weight.t(), use_gelu=False)
+    y = torch.addmm(bias, cat, weight.t())
+    return y.relu_() if relu else y
+
+
+_FUSED_EPILOGUE = hasattr(torch, "_addmm_activation") and not _os.environ.get("CSLICER_NO_FUSED_EPILOGUE")
+
+
+class _SageLayerLocal(torch.autograd.Function):
+    """A whole DistSageConv layer (+ ReLU) of a single part (nothing to exchange) as ONE autograd node over the
+    fused HIP kernels: forward = csl_sage_cat_f32 (self gather + CSR mean straight into the GEMM operand; the
+    deepest layer reads the resident feature table through `rowmap` = the slice's in_nodes, so the gathered
+    input matrix never exists) + one GEMM with bias/ReLU epilogue; backward = csl_relu_bwd_colsum_f32 (ReLU
+    mask + row padding + bias gradient), the slab-wise weight-gradient GEMM, the input-gradient GEMM and
+    csl_sage_cat_bwd_f32.  dist_sageconv.py:42-84 for one GPU."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, self_ids_in, indptr, indices, rowmap, n_out, n_src, relu):
+        m, mp = n_out, _pad_rows(n_out)
+        cat = aggr.sage_cat(x, self_ids_in, m, mp, indptr=indptr, indices=indices, rowmap=rowmap)
+        y = _linear_act(bias, cat, weight, relu)
+        ctx.m, ctx.n_src, ctx.relu = m, n_src, relu
+        ctx.save_for_backward(cat, weight, y if relu else None, self_ids_in, indptr, indices)
+        return y[:m]
+
+    @staticmethod
+    def backward(ctx, gy):
+        cat, weight, y, self_ids_in, indptr, indices = ctx.saved_tensors
+        m, mp = ctx.m, cat.shape[0]
+        gyp, gb = aggr.relu_bwd_colsum(gy, y, m, mp)
+        gw = _weight_grad(gyp, cat)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = aggr.sage_cat_bwd(indptr, indices, self_ids_in, gyp @ weight, m, ctx.n_src)
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
 class DistSageConv(nn.Module):
@@ -224,13 +255,16 @@ class DistSageConv(nn.Module):
 
     def finish_fused(self, sl, agg, x, relu):
         """finish (+ ReLU) as one autograd node (`_SageFinish`); same numbers as finish + torch.relu."""
+        if x.shape[1] % 4:   # the fused operand kernel moves float4 columns
+            y = self.finish(sl, agg, x)
+            return torch.relu(y) if relu else y
         return _SageFinish.apply(x, agg, self.fc.weight, self.fc.bias, sl.self_ids_in, sl.owned_out_nodes,
                                  sl.owned_degree, relu)
 
-    def layer_local(self, sl, x, relu):
+    def layer_local(self, sl, x, relu, rowmap=None):
         """A whole layer of a single part (n_parts == 1: nothing to exchange) as one autograd node."""
-        return _SageFinish.apply(x, None, self.fc.weight, self.fc.bias, sl.self_ids_in, sl.owned_out_nodes,
-                                 sl.owned_degree, relu, sl.indptr, sl.indices, sl.n_out)
+        return _SageLayerLocal.apply(x, self.fc.weight, self.fc.bias, sl.self_ids_in, sl.indptr, sl.indices, rowmap,
+                                     sl.n_out, sl.n_in, relu)
 
     def finish(self, sl, agg, x):
         """slice_owned_nodes + mean + self_gather + concat + Linear."""
@@ -268,7 +302,7 @@ class DistSAGEModel(nn.Module):
         x = {g: feats[g] for g in parts}
         for k, conv in enumerate(self.convs):
             sl = slices[L - 1 - k]
-            if len(parts) == 1 and sl[parts[0]].n_parts == 1 and not _NO_LOCAL_FUSE:
+            if len(parts) == 1 and sl[parts[0]].n_parts == 1 and not _NO_LOCAL_FUSE and x[parts[0]].shape[1] % 4 == 0:
                 x = {parts[0]: conv.layer_local(sl[parts[0]], x[parts[0]], k + 1 < len(self.convs))}
                 continue
             agg = {g: conv.local(sl[g], x[g]) for g in parts}
@@ -276,6 +310,16 @@ class DistSAGEModel(nn.Module):
             for g in parts:
                 agg[g] = conv.merge(sl[g], agg[g], [send[p][g] if p != g else None for p in parts])
             x = {g: conv.finish_fused(sl[g], agg[g], x[g], k + 1 < len(self.convs)) for g in parts}
+        return x
+
+    def forward_local(self, slices, feat_table, part=0):
+        """A single part holding every node (one GPU): each layer is one `_SageLayerLocal` node.  `feat_table` is
+        the resident [N, F] feature matrix; the deepest layer indexes it through its slice's in_nodes."""
+        L = len(slices)
+        x, rowmap = feat_table, slices[L - 1][part].in_nodes
+        for k, conv in enumerate(self.convs):
+            x = conv.layer_local(slices[L - 1 - k][part], x, k + 1 < len(self.convs), rowmap)
+            rowmap = None
         return x
 
     def forward_rank(self, slices, feat, rank, comm, overlap=False):

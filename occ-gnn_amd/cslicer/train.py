@@ -68,27 +68,38 @@ class Trainer(object):
         _roctx.pop()
         self.t_slice += time.perf_counter() - t0
         deep = slices[self.L - 1][self.rank]
-        # gather of owned input features (row v // P of the owner v % P), int32 indices, float4 row kernel
-        _roctx.push("gather")
-        rows = deep.in_nodes if self.P == 1 else torch.div(deep.in_nodes, self.P, rounding_mode="floor")
-        x = aggr.gather_rows(self.feat, rows)
-        _roctx.pop()
-        t1 = time.perf_counter()
-        _roctx.push("forward")
-        if self.rank_path:
-            if self.kind == "gat":
-                logits = self.model.forward_rank(slices, x, self.rank, self.comm)
-            else:
-                logits = self.model.forward_rank(slices, x, self.rank, self.comm, overlap=self.overlap)
-        else:
-            logits = self.model.forward_parts(slices, {0: x})[0]
         top = slices[0][self.rank]
-        seeds = top.out_nodes[top.owned_out_nodes.long()]  # the seeds this rank owns, frontier order
-        y = self.labels[(seeds // self.P).long()]
-        # mean over the WHOLE minibatch: sum of local losses / global seed count
         n_seeds = int(meta.n_seeds)
-        loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / max(n_seeds, 1)
-        _roctx.pop()
+        fused = (not self.rank_path and self.kind == "sage" and self.P == 1 and self.feat.shape[1] % 4 == 0
+                 and not splitgnn._NO_LOCAL_FUSE)
+        if fused:
+            # one GPU holding every node: the deepest layer reads the resident feature table through the slice's
+            # in_nodes (no gathered input matrix), every layer is one fused node, the loss is one HIP pass
+            t1 = time.perf_counter()
+            _roctx.push("forward")
+            logits = self.model.forward_local(slices, self.feat)
+            loss = aggr.SoftmaxCE.apply(logits, top.out_nodes, self.labels, 1.0 / max(n_seeds, 1))
+            _roctx.pop()
+        else:
+            # gather of owned input features (row v // P of the owner v % P), int32 indices, float4 row kernel
+            _roctx.push("gather")
+            rows = deep.in_nodes if self.P == 1 else torch.div(deep.in_nodes, self.P, rounding_mode="floor")
+            x = aggr.gather_rows(self.feat, rows)
+            _roctx.pop()
+            t1 = time.perf_counter()
+            _roctx.push("forward")
+            if self.rank_path:
+                if self.kind == "gat":
+                    logits = self.model.forward_rank(slices, x, self.rank, self.comm)
+                else:
+                    logits = self.model.forward_rank(slices, x, self.rank, self.comm, overlap=self.overlap)
+            else:
+                logits = self.model.forward_parts(slices, {0: x})[0]
+            seeds = top.out_nodes[top.owned_out_nodes.long()]  # the seeds this rank owns, frontier order
+            y = self.labels[(seeds // self.P).long()]
+            # mean over the WHOLE minibatch: sum of local losses / global seed count
+            loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / max(n_seeds, 1)
+            _roctx.pop()
         self.t_forward += time.perf_counter() - t1
         _roctx.push("backward")
         self.opt.zero_grad(set_to_none=True)

@@ -285,6 +285,190 @@ __global__ __launch_bounds__(BLK) void k_gat_bwd(const int* __restrict__ indptr,
   }
 }
 
+// ---- fused GraphSAGE layer pieces (one part per GPU and the single-GPU trainer) --------------------------
+// k_sage_cat: builds the operand of Linear(2*in, out) in ONE pass (dist_sageconv.py:66-80: self_gather, gather,
+// slice_owned_nodes, mean, concat):
+//   cat[r, 0:H)   = act(x[map(self_ids[r])])
+//   cat[r, H:2H)  = 1/max(deg_r,1) * sum over the CSR row of act(x[map(indices[e])])      (indptr != null)
+//                 = 1/max(deg[r],1) * agg[owned[r]]                                       (indptr == null: the sums
+//                                                                         were merged across parts beforehand)
+// map(i) = rowmap ? rowmap[i] : i  (the deepest layer reads the resident feature table through the slice's
+// in_nodes, so the gathered input matrix is never materialised); act = ReLU when relu_in (the previous
+// layer's pre-activation output is consumed directly: no separate activation pass).  Rows [n, n_pad) are zeroed.
+template <int G>
+__global__ __launch_bounds__(BLK) void k_sage_cat(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                  const int* __restrict__ self_ids, const int* __restrict__ owned,
+                                                  const int* __restrict__ deg, const int* __restrict__ rowmap,
+                                                  const float* __restrict__ x, long long ldx,
+                                                  const float* __restrict__ agg, long long lda, long long n,
+                                                  long long n_pad, float* __restrict__ cat, long long ldc, int H,
+                                                  int relu_in) {
+  constexpr int RPB = BLK / G;
+  const int lane = threadIdx.x % G;
+  const long long r = (long long)blockIdx.x * RPB + threadIdx.x / G;
+  if (r >= n_pad) return;
+  float* out = cat + r * ldc;
+  if (r >= n) {
+    for (int c = lane * 4; c < 2 * H; c += G * 4) *reinterpret_cast<float4*>(out + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  const float lo = relu_in ? 0.f : -__builtin_inff();
+  const long long sid = self_ids[r];
+  const long long srow = sid < 0 ? -1 : (rowmap ? (long long)rowmap[sid] : sid);
+  long long e0 = 0, e1 = 0;
+  if (indptr) {
+    e0 = indptr[r];
+    e1 = indptr[r + 1];
+  }
+  const long long d = deg ? (long long)deg[r] : (e1 - e0);
+  const float inv = 1.0f / (float)(d > 1 ? d : 1);
+  for (int c = lane * 4; c < H; c += G * 4) {
+    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (srow >= 0) {
+      sv = *reinterpret_cast<const float4*>(x + srow * ldx + c);
+      sv.x = fmaxf(sv.x, lo), sv.y = fmaxf(sv.y, lo), sv.z = fmaxf(sv.z, lo), sv.w = fmaxf(sv.w, lo);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (indptr) {
+      long long e = e0;
+      for (; e + 4 <= e1; e += 4) {  // four source rows in flight per lane, fixed summation order
+        long long s0 = indices[e], s1 = indices[e + 1], s2 = indices[e + 2], s3 = indices[e + 3];
+        if (rowmap) s0 = rowmap[s0], s1 = rowmap[s1], s2 = rowmap[s2], s3 = rowmap[s3];
+        float4 v0 = *reinterpret_cast<const float4*>(x + s0 * ldx + c);
+        float4 v1 = *reinterpret_cast<const float4*>(x + s1 * ldx + c);
+        float4 v2 = *reinterpret_cast<const float4*>(x + s2 * ldx + c);
+        float4 v3 = *reinterpret_cast<const float4*>(x + s3 * ldx + c);
+        acc.x += fmaxf(v0.x, lo), acc.y += fmaxf(v0.y, lo), acc.z += fmaxf(v0.z, lo), acc.w += fmaxf(v0.w, lo);
+        acc.x += fmaxf(v1.x, lo), acc.y += fmaxf(v1.y, lo), acc.z += fmaxf(v1.z, lo), acc.w += fmaxf(v1.w, lo);
+        acc.x += fmaxf(v2.x, lo), acc.y += fmaxf(v2.y, lo), acc.z += fmaxf(v2.z, lo), acc.w += fmaxf(v2.w, lo);
+        acc.x += fmaxf(v3.x, lo), acc.y += fmaxf(v3.y, lo), acc.z += fmaxf(v3.z, lo), acc.w += fmaxf(v3.w, lo);
+      }
+      for (; e < e1; e++) {
+        long long s0 = indices[e];
+        if (rowmap) s0 = rowmap[s0];
+        const float4 v0 = *reinterpret_cast<const float4*>(x + s0 * ldx + c);
+        acc.x += fmaxf(v0.x, lo), acc.y += fmaxf(v0.y, lo), acc.z += fmaxf(v0.z, lo), acc.w += fmaxf(v0.w, lo);
+      }
+    } else {
+      acc = *reinterpret_cast<const float4*>(agg + (long long)owned[r] * lda + c);
+    }
+    acc.x *= inv, acc.y *= inv, acc.z *= inv, acc.w *= inv;
+    *reinterpret_cast<float4*>(out + c) = sv;
+    *reinterpret_cast<float4*>(out + H + c) = acc;
+  }
+}
+
+// k_sage_cat_bwd: gradient of k_sage_cat (CSR form) w.r.t. x, accumulated with fp32 atomics into a zeroed gx:
+//   gx[self_ids[r]] += gcat[r, 0:H),   gx[indices[e]] += gcat[r, H:2H) / max(deg_r, 1) for every edge of row r.
+// One wave per output row, 64 consecutive floats per atomic instruction (as k_spmm_sum_bwd).  When the layer
+// consumed a pre-activation input (relu_in) the caller masks gx afterwards (k_relu_bwd_colsum of the layer below).
+__global__ __launch_bounds__(BLK) void k_sage_cat_bwd(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                      const int* __restrict__ self_ids, long long n,
+                                                      const float* __restrict__ gcat, long long ldg,
+                                                      float* __restrict__ gx, long long ldx, int H) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const long long e0 = indptr[r], e1 = indptr[r + 1];
+  const float inv = 1.0f / (float)(e1 - e0 > 1 ? e1 - e0 : 1);
+  const long long sid = self_ids[r];
+  for (int c = lane; c < H; c += 64) {
+    if (sid >= 0) atomicAdd(gx + sid * ldx + c, gcat[r * ldg + c]);
+    const float v = gcat[r * ldg + H + c] * inv;
+    for (long long e = e0; e < e1; e++) atomicAdd(gx + (long long)indices[e] * ldx + c, v);
+  }
+}
+
+// k_relu_bwd_colsum: out[r, :] = y ? (y[r, :] > 0 ? g[r, :] : 0) : g[r, :] for r < n, zero rows up to n_pad, and
+// colsum[c] += sum_r out[r, c] (the bias gradient): ReLU backward, the row padding of the GEMM operand and the
+// bias reduction in one pass over the gradient.  colsum must be zero on entry.
+template <int G>
+__global__ __launch_bounds__(BLK) void k_relu_bwd_colsum(const float* __restrict__ g, long long ldg,
+                                                         const float* __restrict__ y, long long ldy, long long n,
+                                                         long long n_pad, float* __restrict__ out, long long ldo,
+                                                         float* __restrict__ colsum, int H, int rows_per_block,
+                                                         int vec) {
+  constexpr int RPB = BLK / G;  // rows in flight per block
+  const int lane = threadIdx.x % G, sub = threadIdx.x / G;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  __shared__ float s_sum[BLK * 4];
+  // (the column loop is block-uniform: every thread reaches the barriers)
+  for (int c0 = 0; c0 < H; c0 += G * 4) {
+    const int c = c0 + lane * 4;
+    const bool full = vec && c + 3 < H;  // aligned float4 accesses, else element-wise with bounds
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long r = r0 + sub; r < r0 + rows_per_block && r < n_pad; r += RPB) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < n) {
+        if (full) {
+          v = *reinterpret_cast<const float4*>(g + r * ldg + c);
+        } else {
+          if (c < H) v.x = g[r * ldg + c];
+          if (c + 1 < H) v.y = g[r * ldg + c + 1];
+          if (c + 2 < H) v.z = g[r * ldg + c + 2];
+          if (c + 3 < H) v.w = g[r * ldg + c + 3];
+        }
+        if (y) {
+          float4 a = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (full) {
+            a = *reinterpret_cast<const float4*>(y + r * ldy + c);
+          } else {
+            if (c < H) a.x = y[r * ldy + c];
+            if (c + 1 < H) a.y = y[r * ldy + c + 1];
+            if (c + 2 < H) a.z = y[r * ldy + c + 2];
+            if (c + 3 < H) a.w = y[r * ldy + c + 3];
+          }
+          v.x = a.x > 0.f ? v.x : 0.f, v.y = a.y > 0.f ? v.y : 0.f, v.z = a.z > 0.f ? v.z : 0.f, v.w = a.w > 0.f ? v.w : 0.f;
+        }
+        add4(acc, v);
+      }
+      if (full) {
+        *reinterpret_cast<float4*>(out + r * ldo + c) = v;
+      } else {
+        if (c < H) out[r * ldo + c] = v.x;
+        if (c + 1 < H) out[r * ldo + c + 1] = v.y;
+        if (c + 2 < H) out[r * ldo + c + 2] = v.z;
+        if (c + 3 < H) out[r * ldo + c + 3] = v.w;
+      }
+    }
+    // the RPB row groups of the block hold partial sums of the same columns
+    __syncthreads();
+    reinterpret_cast<float4*>(s_sum)[threadIdx.x] = acc;
+    __syncthreads();
+    if (sub == 0) {
+      for (int k = 1; k < RPB; k++) add4(acc, reinterpret_cast<float4*>(s_sum)[k * G + lane]);
+      if (c < H) atomicAdd(colsum + c, acc.x);
+      if (c + 1 < H) atomicAdd(colsum + c + 1, acc.y);
+      if (c + 2 < H) atomicAdd(colsum + c + 2, acc.z);
+      if (c + 3 < H) atomicAdd(colsum + c + 3, acc.w);
+    }
+  }
+}
+
+// k_softmax_ce: cross-entropy of one minibatch (train.py:86 loss_fn) forward AND backward in one pass:
+//   loss += -scale * log softmax(logits[r])[label_r],   grad[r, :] = scale * (softmax(logits[r]) - onehot(label_r))
+// label_r = labels[rowmap ? rowmap[ids[r]] : ids[r]] (ids = the seeds' node ids).  One wave per row (C <= 4096).
+__global__ __launch_bounds__(BLK) void k_softmax_ce(const float* __restrict__ logits, long long ldl, long long n, int C,
+                                                    const int* __restrict__ ids, const int* __restrict__ rowmap,
+                                                    const long long* __restrict__ labels, float scale,
+                                                    float* __restrict__ loss, float* __restrict__ grad, long long ldgr) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float* z = logits + r * ldl;
+  float m = -__builtin_inff();
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, z[c]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(z[c] - m);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const long long node = ids[r];
+  const long long lab = labels[rowmap ? (long long)rowmap[node] : node];
+  const float inv = 1.0f / s;
+  for (int c = lane; c < C; c += 64) grad[r * ldgr + c] = scale * (expf(z[c] - m) * inv - (c == lab ? 1.f : 0.f));
+  if (lane == 0) atomicAdd(loss, scale * (logf(s) + m - z[lab]));
+}
+
 int group_for(int H) {
   int q = (H + 3) / 4, g = 1;
   while (g < q && g < 64) g <<= 1;
@@ -391,6 +575,79 @@ int csl_gat_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_row
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gat_bwd, dim3((unsigned)((n_rows + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, indptr,
                      indices, (long long)n_rows, el, er, z, (int)H, (int)D, slope, m_in, g_s, g_n, g_el, g_er, g_z);
+  return done();
+}
+
+
+int csl_sage_cat_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* owned,
+                     const int32_t* deg, const int32_t* rowmap, const float* x, int64_t ldx, const float* agg,
+                     int64_t lda, int64_t n, int64_t n_pad, float* cat, int64_t ldc, int32_t H, int32_t relu_in,
+                     void* stream) {
+  if (n_pad == 0) return CSL_OK;
+  if (n < 0 || n_pad < n || H < 4 || H % 4 != 0 || !cat || ldc < 2 * (int64_t)H || ldc % 4 != 0 || !aligned16(cat))
+    return CSL_E_INVALID;
+  if (n > 0) {
+    if (!self_ids || !x || ldx < H || ldx % 4 != 0 || !aligned16(x)) return CSL_E_INVALID;
+    if (!indptr && (!owned || !deg || !agg || lda < H || lda % 4 != 0 || !aligned16(agg))) return CSL_E_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int G = group_for(H);
+  DISPATCH_G(G, k_sage_cat, n_pad, indptr, indices, self_ids, owned, deg, rowmap, x, (long long)ldx, agg, (long long)lda,
+             (long long)n, (long long)n_pad, cat, (long long)ldc, (int)H, (int)relu_in);
+  return done();
+}
+
+int csl_sage_cat_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, int64_t n,
+                         const float* gcat, int64_t ldg, float* gx, int64_t ldx, int64_t n_src, int32_t H,
+                         void* stream) {
+  if (n < 0 || n_src < 0 || H < 1 || !gx || ldx < H) return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_src > 0 && hipMemsetAsync(gx, 0, sizeof(float) * (size_t)n_src * (size_t)ldx, st) != hipSuccess) return CSL_E_HIP;
+  if (n == 0) return CSL_OK;
+  if (!indptr || !self_ids || !gcat || ldg < 2 * (int64_t)H) return CSL_E_INVALID;
+  hipLaunchKernelGGL(k_sage_cat_bwd, dim3((unsigned)((n + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, indptr, indices,
+                     self_ids, (long long)n, gcat, (long long)ldg, gx, (long long)ldx, (int)H);
+  return done();
+}
+
+int csl_relu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t n, int64_t n_pad,
+                            float* out, int64_t ldo, float* colsum, int32_t H, void* stream) {
+  if (n < 0 || n_pad < n || H < 1 || !colsum) return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)H, st) != hipSuccess) return CSL_E_HIP;
+  if (n_pad == 0) return CSL_OK;
+  if (!out || ldo < H || (n > 0 && (!g || ldg < H)) || (y && ldy < H)) return CSL_E_INVALID;
+  const int G = group_for(H);
+  const int rpb = 64;  // rows per block: a multiple of BLK / G for every G
+  const long long blocks = (n_pad + rpb - 1) / rpb;
+  const int vec = (H % 4 == 0) && (ldg % 4 == 0) && (ldo % 4 == 0) && (!y || ldy % 4 == 0) && aligned16(g) &&
+                  aligned16(out) && (!y || aligned16(y));
+#define LAUNCH_RBC(GG)                                                                                         \
+  hipLaunchKernelGGL(k_relu_bwd_colsum<GG>, dim3((unsigned)blocks), dim3(BLK), 0, st, g, (long long)ldg, y,    \
+                     (long long)ldy, (long long)n, (long long)n_pad, out, (long long)ldo, colsum, (int)H, rpb, vec)
+  switch (G) {
+    case 1: LAUNCH_RBC(4); break;   // (at least 4 lanes per row keeps 64 rows in flight per block)
+    case 2: LAUNCH_RBC(4); break;
+    case 4: LAUNCH_RBC(4); break;
+    case 8: LAUNCH_RBC(8); break;
+    case 16: LAUNCH_RBC(16); break;
+    case 32: LAUNCH_RBC(32); break;
+    default: LAUNCH_RBC(64); break;
+  }
+#undef LAUNCH_RBC
+  return done();
+}
+
+int csl_softmax_ce_f32(const float* logits, int64_t ldl, int64_t n, int32_t C, const int32_t* ids, const int32_t* rowmap,
+                       const int64_t* labels, float scale, float* loss, float* grad, int64_t ldgr, void* stream) {
+  if (n < 0 || C < 1 || !loss) return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return CSL_E_HIP;
+  if (n == 0) return CSL_OK;
+  if (!logits || !ids || !labels || !grad || ldl < C || ldgr < C) return CSL_E_INVALID;
+  hipLaunchKernelGGL(k_softmax_ce, dim3((unsigned)((n + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, logits,
+                     (long long)ldl, (long long)n, (int)C, ids, rowmap, (const long long*)labels, scale, loss, grad,
+                     (long long)ldgr);
   return done();
 }
 

@@ -257,3 +257,106 @@ def test_empty_lists_are_no_ops(mods):
     g = aggr.spmm_sum_bwd(ip, empty, torch.zeros((0, 8), device="cuda"), 10, rows=empty, compact=True)
     assert g.shape == (10, 8) and float(g.abs().sum()) == 0.0
     aggr.div_rows_(torch.zeros((0, 8), device="cuda"), empty)
+
+
+@pytest.mark.parametrize("H,use_map,relu_in", [(4, False, False), (100, True, False), (256, False, True), (32, True, True)])
+def test_sage_cat_forward_backward(mods, H, use_map, relu_in):
+    """csl_sage_cat_f32 / csl_sage_cat_bwd_f32 (self gather + CSR mean straight into the GEMM operand, optional
+    indirection through a row map, optional ReLU on load) against the torch op chain; 1e-5 forward, 1e-4 backward
+    (fp32 atomics: summation order differs)."""
+    _, aggr, _ = mods
+    rng = np.random.default_rng(H)
+    n, n_in, n_tab, n_pad = 700, 900, 1500, 1024
+    indptr, indices = _rand_csr(n, n_in, 12, rng)
+    self_ids = rng.permutation(n_in)[:n].astype(np.int32)
+    self_ids[::11] = -1
+    rowmap = rng.permutation(n_tab)[:n_in].astype(np.int32) if use_map else None
+    x = torch.randn(n_tab if use_map else n_in, H)
+    ip, ix, si = (torch.from_numpy(a).int().cuda() for a in (indptr, indices, self_ids))
+    rm = torch.from_numpy(rowmap).cuda() if use_map else None
+    xr = x.clone().requires_grad_()
+    h = torch.relu(xr) if relu_in else xr
+    src = h[torch.from_numpy(rowmap).long()] if use_map else h
+    rows = torch.repeat_interleave(torch.arange(n), torch.from_numpy(np.diff(indptr)))
+    summed = torch.zeros(n, H).index_add(0, rows, src[torch.from_numpy(indices).long()])
+    deg = torch.from_numpy(np.diff(indptr)).clamp_min(1).float()
+    selfrows = torch.where(torch.from_numpy(self_ids)[:, None] >= 0, src[torch.from_numpy(self_ids).clamp_min(0).long()],
+                           torch.zeros(1, H))
+    ref = torch.cat([selfrows, summed / deg[:, None]], dim=1)
+    cat = aggr.sage_cat(x.cuda(), si, n, n_pad, indptr=ip, indices=ix, rowmap=rm, relu_in=relu_in)
+    assert cat.shape == (n_pad, 2 * H) and float(cat[n:].abs().sum()) == 0.0
+    torch.testing.assert_close(cat[:n].cpu(), ref.detach(), **TOL)
+    if not use_map and not relu_in:
+        g = torch.randn(n_pad, 2 * H)
+        ref.backward(g[:n])
+        gx = aggr.sage_cat_bwd(ip, ix, si, g.cuda(), n, n_in)
+        torch.testing.assert_close(gx.cpu(), xr.grad, rtol=1e-4, atol=2e-5)
+    # the merged-sums form (one part of several): agg[owned] / deg next to the self rows
+    owned = torch.from_numpy(rng.permutation(n + 30)[:n].astype(np.int32)).cuda()
+    degs = torch.from_numpy(rng.integers(0, 9, size=n).astype(np.int32)).cuda()
+    agg = torch.randn(n + 30, H, device="cuda")
+    cat2 = aggr.sage_cat(x.cuda(), si, n, n, owned=owned, deg=degs, agg=agg, rowmap=rm, relu_in=relu_in)
+    torch.testing.assert_close(cat2[:, :H].cpu(), selfrows.detach(), **TOL)
+    torch.testing.assert_close(cat2[:, H:], agg[owned.long()] / degs.clamp_min(1)[:, None].float(), **TOL)
+
+
+@pytest.mark.parametrize("H,n,n_pad,masked", [(256, 5000, 8192, True), (47, 1024, 1024, False), (3, 130, 200, True),
+                                              (100, 77, 77, True)])
+def test_relu_bwd_colsum(mods, H, n, n_pad, masked):
+    _, aggr, _ = mods
+    torch.manual_seed(H)
+    g = torch.randn(n, H, device="cuda")
+    y = torch.randn(n_pad, H, device="cuda") if masked else None
+    out, cs = aggr.relu_bwd_colsum(g, y, n, n_pad)
+    want = g * (y[:n] > 0) if masked else g
+    assert out.shape == (n_pad, H) and float(out[n:].abs().sum()) == 0.0
+    assert torch.equal(out[:n], want)
+    torch.testing.assert_close(cs, want.double().sum(0).float(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("C_,use_map", [(47, False), (7, True), (172, False)])
+def test_softmax_ce_matches_torch(mods, C_, use_map):
+    _, aggr, _ = mods
+    torch.manual_seed(C_)
+    n, N = 1000, 5000
+    logits = (4 * torch.randn(n, C_, device="cuda")).requires_grad_()
+    ids = torch.randperm(N, device="cuda")[:n].int()
+    labels = torch.randint(0, C_, (N,), device="cuda")
+    rowmap = torch.randperm(N, device="cuda").int() if use_map else None
+    lab = labels[rowmap[ids.long()].long()] if use_map else labels[ids.long()]
+    ref_in = logits.detach().clone().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(ref_in, lab, reduction="sum") / n
+    (ref * 3.0).backward()
+    loss = aggr.SoftmaxCE.apply(logits, ids, labels, 1.0 / n, rowmap)
+    (loss * 3.0).backward()
+    torch.testing.assert_close(loss.detach(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(logits.grad, ref_in.grad, rtol=1e-5, atol=1e-7)
+
+
+def test_fused_local_model_reads_the_feature_table(mods):
+    """DistSAGEModel.forward_local (every layer one fused node, the deepest one indexing the resident feature table
+    through the slice's in_nodes) == forward_parts on the gathered features, forward and weight gradients."""
+    abi, aggr, sg = mods
+    from cslicer import l0
+    torch.manual_seed(1)
+    n, F0, hidden, classes, B = 4000, 24, 32, 5, 128
+    indptr, indices = l0.synth_graph(n, 15.0, seed=9)
+    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(6, 5, 4), max_batch=B, mode=abi.MODE_GRAPH)
+    eng.submit_seeds([np.random.default_rng(3).permutation(n)[:B]])
+    slices = sg.slices_of(eng)
+    feats = torch.randn(n, F0, device="cuda")
+    model = sg.DistSAGEModel(F0, hidden, classes, n_layers=3).cuda()
+    w = torch.randn(B, classes, device="cuda")
+    grads = []
+    for local in (True, False):
+        model.zero_grad()
+        if local:
+            out = model.forward_local(slices, feats)
+        else:
+            out = model.forward_parts(slices, {0: feats[slices[2][0].in_nodes.long()]})[0]
+        (out * w).sum().backward()
+        grads.append((out.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    torch.testing.assert_close(grads[0][0], grads[1][0], **TOL)
+    for a_, b_ in zip(grads[0][1], grads[1][1]):
+        torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-5)
+    eng.close()
