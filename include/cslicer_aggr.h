@@ -90,15 +90,20 @@ int csl_sage_cat_bwd_f32(const int32_t* indptr, const int32_t* indices, const in
                          void* stream);
 
 /* out[r, :] = (y == NULL || y[r, :] > 0) ? g[r, :] : 0 for r < n, zero rows for n <= r < n_pad;
- * colsum[c] = sum_r out[r, c] (zeroed here first): ReLU backward + row padding of the GEMM operand + bias gradient. */
+ * colsum[c] = sum_r out[r, c]: ReLU backward + row padding of the GEMM operand + bias gradient in one pass
+ * (two-stage reduction, no atomics, nothing to pre-zero).  scratch: csl_relu_bwd_colsum_scratch(n_pad, H) floats. */
+int64_t csl_relu_bwd_colsum_scratch(int64_t n_pad, int32_t H);
 int csl_relu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t n, int64_t n_pad,
-                            float* out, int64_t ldo, float* colsum, int32_t H, void* stream);
+                            float* out, int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream);
 
-/* cross-entropy (python/train.py:86), forward and backward in one pass: *loss (zeroed here first) =
- * -scale * sum_r log softmax(logits[r])[label_r]; grad[r, :] = scale * (softmax(logits[r]) - onehot(label_r));
- * label_r = labels[rowmap ? rowmap[ids[r]] : ids[r]] (int64 labels, int32 node ids). */
+/* cross-entropy (python/train.py:86), forward and backward in one pass:
+ * *loss = -scale * sum_r log softmax(logits[r])[label_r]; grad[r, :] = scale * (softmax(logits[r]) - onehot(label_r));
+ * label_r = labels[rowmap ? rowmap[ids[r]] : ids[r]] (int64 labels, int32 node ids).
+ * scratch: csl_softmax_ce_scratch(n) floats. */
+int64_t csl_softmax_ce_scratch(int64_t n);
 int csl_softmax_ce_f32(const float* logits, int64_t ldl, int64_t n, int32_t C, const int32_t* ids, const int32_t* rowmap,
-                       const int64_t* labels, float scale, float* loss, float* grad, int64_t ldgr, void* stream);
+                       const int64_t* labels, float scale, float* loss, float* grad, int64_t ldgr, float* scratch,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,8 @@ from . import _abi
 
 SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_scatter_add_rows_f32", "csl_div_rows_f32", "csl_gat_fwd_f32", "csl_gat_bwd_f32",
-           "csl_sage_cat_f32", "csl_sage_cat_bwd_f32", "csl_relu_bwd_colsum_f32", "csl_softmax_ce_f32"]
+           "csl_sage_cat_f32", "csl_sage_cat_bwd_f32", "csl_relu_bwd_colsum_f32", "csl_softmax_ce_f32",
+           "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch"]
 _ready = False
 
 
@@ -32,8 +33,12 @@ def _lib():
         L.csl_gat_bwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
         L.csl_sage_cat_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, vp, i64, i32, i32, vp]
         L.csl_sage_cat_bwd_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, i64, i32, vp]
-        L.csl_relu_bwd_colsum_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, i64, vp, i32, vp]
-        L.csl_softmax_ce_f32.argtypes = [vp, i64, i64, i32, vp, vp, vp, f32, vp, vp, i64, vp]
+        L.csl_relu_bwd_colsum_f32.argtypes = [vp, i64, vp, i64, i64, i64, vp, i64, vp, vp, i32, vp]
+        L.csl_relu_bwd_colsum_scratch.argtypes = [i64, i32]
+        L.csl_relu_bwd_colsum_scratch.restype = i64
+        L.csl_softmax_ce_f32.argtypes = [vp, i64, i64, i32, vp, vp, vp, f32, vp, vp, i64, vp, vp]
+        L.csl_softmax_ce_scratch.argtypes = [i64]
+        L.csl_softmax_ce_scratch.restype = i64
         _ready = True
     return L
 
@@ -170,11 +175,14 @@ def relu_bwd_colsum(g, y, n, n_pad):
     g = _f32(g)
     H = g.shape[1]
     out = torch.empty((n_pad, H), dtype=torch.float32, device=g.device)
-    colsum = torch.empty((H,), dtype=torch.float32, device=g.device)
-    _chk(_lib().csl_relu_bwd_colsum_f32(_p(g), g.stride(0), _p(y) if y is not None else C.c_void_p(0),
-                                        y.stride(0) if y is not None else 0, n, n_pad, _p(out), out.stride(0),
-                                        _p(colsum), H, _stream()), "csl_relu_bwd_colsum_f32")
-    return out, colsum
+    L = _lib()
+    # colsum and the per-block partial sums share one allocation
+    buf = torch.empty((H + max(int(L.csl_relu_bwd_colsum_scratch(n_pad, H)), 1),), dtype=torch.float32, device=g.device)
+    _chk(L.csl_relu_bwd_colsum_f32(_p(g), g.stride(0), _p(y) if y is not None else C.c_void_p(0),
+                                   y.stride(0) if y is not None else 0, n, n_pad, _p(out), out.stride(0),
+                                   C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr() + 4 * H), H, _stream()),
+         "csl_relu_bwd_colsum_f32")
+    return out, buf[:H]
 
 
 class SoftmaxCE(torch.autograd.Function):
@@ -185,16 +193,17 @@ class SoftmaxCE(torch.autograd.Function):
     def forward(ctx, logits, ids, labels, scale, rowmap=None):
         logits = _f32(logits)
         n, Cn = logits.shape
-        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        L = _lib()
+        buf = torch.empty((1 + max(int(L.csl_softmax_ce_scratch(n)), 1),), dtype=torch.float32, device=logits.device)
         grad = torch.empty((n, Cn), dtype=torch.float32, device=logits.device)
         if labels.dtype != torch.int64:
             raise TypeError("labels must be int64")
-        _chk(_lib().csl_softmax_ce_f32(_p(logits), logits.stride(0), n, Cn, _p(_i32(ids)),
-                                       _p(rowmap) if rowmap is not None else C.c_void_p(0), _p(labels), float(scale),
-                                       C.c_void_p(loss.data_ptr()), _p(grad), grad.stride(0), _stream()),
-             "csl_softmax_ce_f32")
+        _chk(L.csl_softmax_ce_f32(_p(logits), logits.stride(0), n, Cn, _p(_i32(ids)),
+                                  _p(rowmap) if rowmap is not None else C.c_void_p(0), _p(labels), float(scale),
+                                  C.c_void_p(buf.data_ptr()), _p(grad), grad.stride(0),
+                                  C.c_void_p(buf.data_ptr() + 4), _stream()), "csl_softmax_ce_f32")
         ctx.save_for_backward(grad)
-        return loss
+        return buf[0]
 
     @staticmethod
     def backward(ctx, g):

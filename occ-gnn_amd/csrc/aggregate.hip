@@ -380,55 +380,66 @@ __global__ __launch_bounds__(BLK) void k_sage_cat_bwd(const int* __restrict__ in
 }
 
 // k_relu_bwd_colsum: out[r, :] = y ? (y[r, :] > 0 ? g[r, :] : 0) : g[r, :] for r < n, zero rows up to n_pad, and
-// colsum[c] += sum_r out[r, c] (the bias gradient): ReLU backward, the row padding of the GEMM operand and the
-// bias reduction in one pass over the gradient.  colsum must be zero on entry.
+// the column sums of `out` (the bias gradient): ReLU backward, the row padding of the GEMM operand and the bias
+// reduction in one pass over the gradient.  Two stages, no atomics and nothing to pre-zero: every block leaves the
+// column sums of its RB_ROWS rows in partial[block][H], k_colsum_finish adds the blocks up.
+constexpr int RB_ROWS = 128;  // rows per block
+constexpr int RB_U = 4;       // rows a thread has in flight
 template <int G>
 __global__ __launch_bounds__(BLK) void k_relu_bwd_colsum(const float* __restrict__ g, long long ldg,
                                                          const float* __restrict__ y, long long ldy, long long n,
                                                          long long n_pad, float* __restrict__ out, long long ldo,
-                                                         float* __restrict__ colsum, int H, int rows_per_block,
-                                                         int vec) {
-  constexpr int RPB = BLK / G;  // rows in flight per block
+                                                         float* __restrict__ partial, int H, int vec) {
+  constexpr int RPB = BLK / G;  // row groups of the block
   const int lane = threadIdx.x % G, sub = threadIdx.x / G;
-  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r0 = (long long)blockIdx.x * RB_ROWS;
+  const long long r_end = r0 + RB_ROWS < n_pad ? r0 + RB_ROWS : n_pad;
   __shared__ float s_sum[BLK * 4];
   // (the column loop is block-uniform: every thread reaches the barriers)
   for (int c0 = 0; c0 < H; c0 += G * 4) {
     const int c = c0 + lane * 4;
     const bool full = vec && c + 3 < H;  // aligned float4 accesses, else element-wise with bounds
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long r = r0 + sub; r < r0 + rows_per_block && r < n_pad; r += RPB) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < n) {
-        if (full) {
-          v = *reinterpret_cast<const float4*>(g + r * ldg + c);
-        } else {
-          if (c < H) v.x = g[r * ldg + c];
-          if (c + 1 < H) v.y = g[r * ldg + c + 1];
-          if (c + 2 < H) v.z = g[r * ldg + c + 2];
-          if (c + 3 < H) v.w = g[r * ldg + c + 3];
-        }
-        if (y) {
-          float4 a = make_float4(1.f, 1.f, 1.f, 1.f);
+    for (long long rb = r0 + sub; rb < r_end; rb += RPB * RB_U) {
+      float4 v[RB_U], a[RB_U];
+#pragma unroll
+      for (int u = 0; u < RB_U; u++) {
+        const long long r = rb + (long long)u * RPB;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (r < n) {
           if (full) {
-            a = *reinterpret_cast<const float4*>(y + r * ldy + c);
+            v[u] = *reinterpret_cast<const float4*>(g + r * ldg + c);
+            if (y) a[u] = *reinterpret_cast<const float4*>(y + r * ldy + c);
           } else {
-            if (c < H) a.x = y[r * ldy + c];
-            if (c + 1 < H) a.y = y[r * ldy + c + 1];
-            if (c + 2 < H) a.z = y[r * ldy + c + 2];
-            if (c + 3 < H) a.w = y[r * ldy + c + 3];
+            if (c < H) v[u].x = g[r * ldg + c];
+            if (c + 1 < H) v[u].y = g[r * ldg + c + 1];
+            if (c + 2 < H) v[u].z = g[r * ldg + c + 2];
+            if (c + 3 < H) v[u].w = g[r * ldg + c + 3];
+            if (y) {
+              if (c < H) a[u].x = y[r * ldy + c];
+              if (c + 1 < H) a[u].y = y[r * ldy + c + 1];
+              if (c + 2 < H) a[u].z = y[r * ldy + c + 2];
+              if (c + 3 < H) a[u].w = y[r * ldy + c + 3];
+            }
           }
-          v.x = a.x > 0.f ? v.x : 0.f, v.y = a.y > 0.f ? v.y : 0.f, v.z = a.z > 0.f ? v.z : 0.f, v.w = a.w > 0.f ? v.w : 0.f;
         }
-        add4(acc, v);
       }
-      if (full) {
-        *reinterpret_cast<float4*>(out + r * ldo + c) = v;
-      } else {
-        if (c < H) out[r * ldo + c] = v.x;
-        if (c + 1 < H) out[r * ldo + c + 1] = v.y;
-        if (c + 2 < H) out[r * ldo + c + 2] = v.z;
-        if (c + 3 < H) out[r * ldo + c + 3] = v.w;
+#pragma unroll
+      for (int u = 0; u < RB_U; u++) {
+        const long long r = rb + (long long)u * RPB;
+        if (r >= r_end) continue;
+        float4 w = v[u];
+        w.x = a[u].x > 0.f ? w.x : 0.f, w.y = a[u].y > 0.f ? w.y : 0.f, w.z = a[u].z > 0.f ? w.z : 0.f, w.w = a[u].w > 0.f ? w.w : 0.f;
+        add4(acc, w);
+        if (full) {
+          *reinterpret_cast<float4*>(out + r * ldo + c) = w;
+        } else {
+          if (c < H) out[r * ldo + c] = w.x;
+          if (c + 1 < H) out[r * ldo + c + 1] = w.y;
+          if (c + 2 < H) out[r * ldo + c + 2] = w.z;
+          if (c + 3 < H) out[r * ldo + c + 3] = w.w;
+        }
       }
     }
     // the RPB row groups of the block hold partial sums of the same columns
@@ -437,36 +448,56 @@ __global__ __launch_bounds__(BLK) void k_relu_bwd_colsum(const float* __restrict
     __syncthreads();
     if (sub == 0) {
       for (int k = 1; k < RPB; k++) add4(acc, reinterpret_cast<float4*>(s_sum)[k * G + lane]);
-      if (c < H) atomicAdd(colsum + c, acc.x);
-      if (c + 1 < H) atomicAdd(colsum + c + 1, acc.y);
-      if (c + 2 < H) atomicAdd(colsum + c + 2, acc.z);
-      if (c + 3 < H) atomicAdd(colsum + c + 3, acc.w);
+      float* p = partial + (long long)blockIdx.x * H;
+      if (c < H) p[c] = acc.x;
+      if (c + 1 < H) p[c + 1] = acc.y;
+      if (c + 2 < H) p[c + 2] = acc.z;
+      if (c + 3 < H) p[c + 3] = acc.w;
     }
   }
 }
+// out[c] = sum over the blocks of partial[block][c]: 4 x 64 threads per 64 columns, the four groups split the blocks
+__global__ __launch_bounds__(BLK) void k_colsum_finish(const float* __restrict__ partial, long long nblk, int H,
+                                                       float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  __shared__ float s_q[BLK];
+  float acc = 0.f;
+  if (c < H)
+    for (long long b = q; b < nblk; b += BLK / 64) acc += partial[b * H + c];
+  s_q[threadIdx.x] = acc;
+  __syncthreads();
+  if (q == 0 && c < H) out[c] = s_q[threadIdx.x] + s_q[threadIdx.x + 64] + s_q[threadIdx.x + 128] + s_q[threadIdx.x + 192];
+}
 
 // k_softmax_ce: cross-entropy of one minibatch (train.py:86 loss_fn) forward AND backward in one pass:
-//   loss += -scale * log softmax(logits[r])[label_r],   grad[r, :] = scale * (softmax(logits[r]) - onehot(label_r))
-// label_r = labels[rowmap ? rowmap[ids[r]] : ids[r]] (ids = the seeds' node ids).  One wave per row (C <= 4096).
+//   loss = -scale * sum_r log softmax(logits[r])[label_r],   grad[r, :] = scale * (softmax(logits[r]) - onehot(label_r))
+// label_r = labels[rowmap ? rowmap[ids[r]] : ids[r]] (ids = the seeds' node ids).  One wave per row (C <= 4096); a
+// block leaves the loss of its four rows in partial[block], k_colsum_finish (H = 1) adds the blocks up.
 __global__ __launch_bounds__(BLK) void k_softmax_ce(const float* __restrict__ logits, long long ldl, long long n, int C,
                                                     const int* __restrict__ ids, const int* __restrict__ rowmap,
                                                     const long long* __restrict__ labels, float scale,
-                                                    float* __restrict__ loss, float* __restrict__ grad, long long ldgr) {
-  const int lane = threadIdx.x & 63;
-  const long long r = (long long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
-  if (r >= n) return;
-  const float* z = logits + r * ldl;
-  float m = -__builtin_inff();
-  for (int c = lane; c < C; c += 64) m = fmaxf(m, z[c]);
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  float s = 0.f;
-  for (int c = lane; c < C; c += 64) s += expf(z[c] - m);
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  const long long node = ids[r];
-  const long long lab = labels[rowmap ? (long long)rowmap[node] : node];
-  const float inv = 1.0f / s;
-  for (int c = lane; c < C; c += 64) grad[r * ldgr + c] = scale * (expf(z[c] - m) * inv - (c == lab ? 1.f : 0.f));
-  if (lane == 0) atomicAdd(loss, scale * (logf(s) + m - z[lab]));
+                                                    float* __restrict__ partial, float* __restrict__ grad, long long ldgr) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long r = (long long)blockIdx.x * (BLK / 64) + w;
+  __shared__ float s_l[BLK / 64];
+  float mine = 0.f;
+  if (r < n) {
+    const float* z = logits + r * ldl;
+    float m = -__builtin_inff();
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, z[c]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += expf(z[c] - m);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const long long node = ids[r];
+    const long long lab = labels[rowmap ? (long long)rowmap[node] : node];
+    const float inv = 1.0f / s;
+    for (int c = lane; c < C; c += 64) grad[r * ldgr + c] = scale * (expf(z[c] - m) * inv - (c == lab ? 1.f : 0.f));
+    mine = scale * (logf(s) + m - z[lab]);
+  }
+  if (lane == 0) s_l[w] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_l[0] + s_l[1] + s_l[2] + s_l[3];
 }
 
 int group_for(int H) {
@@ -610,44 +641,50 @@ int csl_sage_cat_bwd_f32(const int32_t* indptr, const int32_t* indices, const in
   return done();
 }
 
+int64_t csl_relu_bwd_colsum_scratch(int64_t n_pad, int32_t H) {
+  return ((n_pad + RB_ROWS - 1) / RB_ROWS) * (int64_t)(H > 0 ? H : 0);
+}
+
 int csl_relu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t n, int64_t n_pad,
-                            float* out, int64_t ldo, float* colsum, int32_t H, void* stream) {
+                            float* out, int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream) {
   if (n < 0 || n_pad < n || H < 1 || !colsum) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)H, st) != hipSuccess) return CSL_E_HIP;
-  if (n_pad == 0) return CSL_OK;
-  if (!out || ldo < H || (n > 0 && (!g || ldg < H)) || (y && ldy < H)) return CSL_E_INVALID;
-  const int G = group_for(H);
-  const int rpb = 64;  // rows per block: a multiple of BLK / G for every G
-  const long long blocks = (n_pad + rpb - 1) / rpb;
-  const int vec = (H % 4 == 0) && (ldg % 4 == 0) && (ldo % 4 == 0) && (!y || ldy % 4 == 0) && aligned16(g) &&
-                  aligned16(out) && (!y || aligned16(y));
+  const long long blocks = (n_pad + RB_ROWS - 1) / RB_ROWS;
+  if (blocks > 0) {
+    if (!scratch || !out || ldo < H || (n > 0 && (!g || ldg < H)) || (y && ldy < H)) return CSL_E_INVALID;
+    const int G = group_for(H);
+    const int vec = (H % 4 == 0) && (ldg % 4 == 0) && (ldo % 4 == 0) && (!y || ldy % 4 == 0) && aligned16(g) &&
+                    aligned16(out) && (!y || aligned16(y));
 #define LAUNCH_RBC(GG)                                                                                         \
   hipLaunchKernelGGL(k_relu_bwd_colsum<GG>, dim3((unsigned)blocks), dim3(BLK), 0, st, g, (long long)ldg, y,    \
-                     (long long)ldy, (long long)n, (long long)n_pad, out, (long long)ldo, colsum, (int)H, rpb, vec)
-  switch (G) {
-    case 1: LAUNCH_RBC(4); break;   // (at least 4 lanes per row keeps 64 rows in flight per block)
-    case 2: LAUNCH_RBC(4); break;
-    case 4: LAUNCH_RBC(4); break;
-    case 8: LAUNCH_RBC(8); break;
-    case 16: LAUNCH_RBC(16); break;
-    case 32: LAUNCH_RBC(32); break;
-    default: LAUNCH_RBC(64); break;
-  }
+                     (long long)ldy, (long long)n, (long long)n_pad, out, (long long)ldo, scratch, (int)H, vec)
+    switch (G) {
+      case 1: case 2: case 4: LAUNCH_RBC(4); break;
+      case 8: LAUNCH_RBC(8); break;
+      case 16: LAUNCH_RBC(16); break;
+      case 32: LAUNCH_RBC(32); break;
+      default: LAUNCH_RBC(64); break;
+    }
 #undef LAUNCH_RBC
+  }
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((H + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, (int)H, colsum);
   return done();
 }
 
+int64_t csl_softmax_ce_scratch(int64_t n) { return (n + BLK / 64 - 1) / (BLK / 64); }
+
 int csl_softmax_ce_f32(const float* logits, int64_t ldl, int64_t n, int32_t C, const int32_t* ids, const int32_t* rowmap,
-                       const int64_t* labels, float scale, float* loss, float* grad, int64_t ldgr, void* stream) {
+                       const int64_t* labels, float scale, float* loss, float* grad, int64_t ldgr, float* scratch,
+                       void* stream) {
   if (n < 0 || C < 1 || !loss) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return CSL_E_HIP;
-  if (n == 0) return CSL_OK;
-  if (!logits || !ids || !labels || !grad || ldl < C || ldgr < C) return CSL_E_INVALID;
-  hipLaunchKernelGGL(k_softmax_ce, dim3((unsigned)((n + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, st, logits,
-                     (long long)ldl, (long long)n, (int)C, ids, rowmap, (const long long*)labels, scale, loss, grad,
-                     (long long)ldgr);
+  const long long blocks = (n + BLK / 64 - 1) / (BLK / 64);
+  if (blocks > 0) {
+    if (!logits || !ids || !labels || !grad || !scratch || ldl < C || ldgr < C) return CSL_E_INVALID;
+    hipLaunchKernelGGL(k_softmax_ce, dim3((unsigned)blocks), dim3(BLK), 0, st, logits, (long long)ldl, (long long)n,
+                       (int)C, ids, rowmap, (const long long*)labels, scale, scratch, grad, (long long)ldgr);
+  }
+  hipLaunchKernelGGL(k_colsum_finish, dim3(1), dim3(BLK), 0, st, scratch, blocks, 1, loss);
   return done();
 }
 
