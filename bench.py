@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--e2e-hidden", type=int, default=256)
     ap.add_argument("--e2e-feat", type=int, default=100)
     ap.add_argument("--e2e-classes", type=int, default=47)
+    ap.add_argument("--e2e-streams", type=int, default=8, help="minibatches the trainer's engine slices per round")
     ap.add_argument("--selftest-dist", choices=("ok", "e2e-fail", "e2e-hang"), default=None,
                     help="no GPU work at all: rendezvous (gloo), reductions, the guarded e2e leg with a stand-in body, "
                          "the single JSON line and the shutdown path -- what tests/test_bench_launch.py runs on CPU")
@@ -448,11 +449,12 @@ def main():
     # ---- end-to-end minibatch rate: slice + feature gather + forward/backward + Adam, one part per GPU
     def e2e_leg():
         from cslicer.train import Trainer, synthetic_node_data
-        feats, labels = synthetic_node_data(N, args.e2e_feat, args.e2e_classes, seed=0)
+        # every rank generates only the feature/label rows of the nodes it owns (counter-based generator)
+        feats = lambda own: synthetic_node_data(N, args.e2e_feat, args.e2e_classes, seed=0, rows=own)[0]  # noqa: E731
+        labels = lambda own: synthetic_node_data(N, 1, args.e2e_classes, seed=0, rows=own)[1]            # noqa: E731
         tr = Trainer(indptr, indices, feats, labels, args.e2e_classes, rank=rank, world=world, fanouts=fan,
-                     batch=B, streams=8, hidden=args.e2e_hidden, device=device, dist=dist,
-                     model=args.e2e_model, heads=args.e2e_heads)
-        del feats
+                     batch=B, streams=args.e2e_streams, hidden=args.e2e_hidden, device=device, dist=dist,
+                     model=args.e2e_model, heads=args.e2e_heads, feat_dim=args.e2e_feat)
         tr.set_nodes(perm)
         tr.run(16)                       # warm-up (allocator, rng window, GEMM heuristics)
         barrier()

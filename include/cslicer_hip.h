@@ -117,6 +117,11 @@ typedef struct {
   int64_t frontier_cap[CSL_MAX_LAYERS + 1];
   int32_t mode;              /* CSL_MODE_STRICT (0) or CSL_MODE_GRAPH */
   int32_t flags;             /* CSL_FLAG_* */
+  /* one process per part: bit g set = the lists of part g are written; 0 = all parts.  Sampling, dedup and every
+   * size/offset in the meta are unaffected (they are global properties of the minibatch); the list CONTENTS of a
+   * part that is masked out are undefined.  A rank of the split-parallel trainer asks for its own part only. */
+  uint32_t part_mask;
+  uint32_t reserved;         /* 0 */
 } csl_config;
 
 /* csl_config.flags */

@@ -58,6 +58,8 @@ class Config(C.Structure):
         ("frontier_cap", C.c_int64 * (MAX_LAYERS + 1)),
         ("mode", C.c_int32),
         ("flags", C.c_int32),
+        ("part_mask", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -151,7 +153,7 @@ class Engine:
 
     def __init__(self, indptr, indices, n_parts=4, fanouts=(10, 10, 10), max_batch=1024,
                  n_streams=1, n_slots=1, workload=None, device=0, rng_seed=5489,
-                 rng_ring_log2=0, frontier_cap=None, mode=MODE_STRICT, flags=0):
+                 rng_ring_log2=0, frontier_cap=None, mode=MODE_STRICT, flags=0, part_mask=0):
         L = load()
         self._h = None
         self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
@@ -182,6 +184,8 @@ class Engine:
         cfg.rng_ring_log2 = rng_ring_log2
         cfg.mode = mode
         cfg.flags = flags
+        cfg.part_mask = part_mask
+        self.part_mask = part_mask
         self.mode = mode
         self.flags = flags
         if frontier_cap is not None:

@@ -40,6 +40,24 @@ def epoch_plan(num_nodes, batch_size, streams, world):
     return plan
 
 
+def round_plan(n_batches, streams, first_batch, n_steps):
+    """(first minibatch, count) of the engine rounds that train `n_steps` minibatches starting at `first_batch`,
+    wrapping around the epoch.  A round holds at most `streams` minibatches and never crosses the end of the
+    epoch, so the tail n_batches % streams of every epoch is one short round and each minibatch of an epoch is
+    taken exactly once (the reference's WorkerPool likewise hands out every batch once per epoch,
+    WorkerPool.cpp:41-50)."""
+    plan = []
+    if n_batches < 1 or n_steps < 1:
+        return plan
+    b, left = first_batch % n_batches, n_steps
+    while left > 0:
+        k = min(streams, n_batches - b, left)
+        plan.append((b, k))
+        b = (b + k) % n_batches
+        left -= k
+    return plan
+
+
 def max_over_ranks(seconds, dist=None, device=None):
     """The job's wall time is the slowest rank's (bench.py contract)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -18,41 +18,70 @@ import time
 import numpy as np
 import torch
 
-from . import _abi, _roctx, aggr, splitgnn
+from . import _abi, _roctx, aggr, shard, splitgnn
 
 
 class Trainer(object):
     def __init__(self, indptr, indices, features, labels, n_classes, rank=0, world=1, fanouts=(15, 10, 5),
                  batch=1024, streams=8, hidden=256, lr=1e-3, device=0, dist=None, seed=0, overlap=False,
-                 model="sage", heads=8, rank_path=None):
-        """features: float32 [N, F] (host, the rank keeps only the rows it owns); labels int64 [N]."""
+                 model="sage", heads=8, rank_path=None, workload=None, feat_dim=None):
+        """Part `rank` of `world`.  Ownership = the engine's workload table (`workload` int32 [N], the METIS map of
+        python/utils/sampler.py:64-134 / partition_map_opt.bin; None = v % world like pyfrontend.cpp:57): the rank
+        keeps the feature and label rows of the nodes it owns, in ascending node order.
+
+        features / labels: either host arrays over ALL nodes (float32 [N, F], int64 [N]; the rank copies its own
+        rows) or callables `f(own_ids) -> rows` so that a rank never holds more than its share (papers100M:
+        57 GB of features over 8 ranks); with a callable `features`, pass `feat_dim`."""
         self.rank, self.world, self.dist = rank, world, dist
         self.P = world
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         N = indptr.shape[0] - 1
         self.N, self.B, self.S, self.L = N, batch, streams, len(fanouts)
+        # rank_path=True forces the one-process-per-part code (collectives included) even for a single part:
+        # a way to run the RCCL calls on a one-GPU box
+        self.rank_path = (world > 1) if rank_path is None else bool(rank_path)
+        if workload is not None:
+            workload = np.ascontiguousarray(workload, dtype=np.int32)
+            if workload.shape != (N,) or workload.min() < 0 or workload.max() >= world:
+                raise ValueError("workload must be int32 [num_nodes] with values in [0, world)")
+        # one process per part: only this rank's slices are materialised (the sampling itself is replicated)
         self.eng = _abi.Engine(indptr, indices, n_parts=self.P, fanouts=fanouts, max_batch=batch,
-                               n_streams=streams, n_slots=2, device=device, mode=_abi.MODE_GRAPH)
-        own = np.arange(rank, N, self.P)
-        self.feat = torch.from_numpy(np.ascontiguousarray(features[own])).to(self.dev)   # row v // P of owner v % P
-        self.labels = torch.from_numpy(np.ascontiguousarray(labels[own])).to(self.dev)
+                               n_streams=streams, n_slots=2, device=device, mode=_abi.MODE_GRAPH,
+                               workload=workload, part_mask=(1 << rank) if self.rank_path else 0)
+        if workload is None:
+            own = np.arange(rank, N, self.P, dtype=np.int64)           # owner v % P holds v at local row v // P
+        else:
+            own = np.flatnonzero(workload == rank).astype(np.int64)   # ascending: local row = rank among owned
+        self.n_own = own.shape[0]
+        take = (lambda a: a(own)) if callable(features) else (lambda a: a[own] if self.P > 1 else a)
+        f_own = np.ascontiguousarray(take(features), dtype=np.float32)
+        l_own = np.ascontiguousarray((labels(own) if callable(labels) else (labels[own] if self.P > 1 else labels)),
+                                     dtype=np.int64)
+        if f_own.shape[0] != self.n_own or l_own.shape[0] != self.n_own:
+            raise ValueError("features / labels do not cover the rank's %d nodes" % self.n_own)
+        F = f_own.shape[1] if feat_dim is None else feat_dim
+        self.feat = torch.from_numpy(f_own).to(self.dev)
+        self.labels = torch.from_numpy(l_own).to(self.dev)
+        del f_own, l_own
+        # global node id -> local row of the owner (-1 elsewhere); a single part holds every node at its own id
+        self.local_row = None
+        if self.P > 1:
+            lr_ = np.full(N, -1, dtype=np.int32)
+            lr_[own] = np.arange(self.n_own, dtype=np.int32)
+            self.local_row = torch.from_numpy(lr_).to(self.dev)
         torch.manual_seed(seed)      # identical replicated weights on every rank
         self.kind = model
         if model == "sage":
-            self.model = splitgnn.DistSAGEModel(features.shape[1], hidden, n_classes, n_layers=self.L).to(self.dev)
+            self.model = splitgnn.DistSAGEModel(F, hidden, n_classes, n_layers=self.L).to(self.dev)
         elif model == "gat":
-            self.model = splitgnn.DistGATModel(features.shape[1], hidden, n_classes, heads=heads,
-                                               n_layers=self.L).to(self.dev)
+            self.model = splitgnn.DistGATModel(F, hidden, n_classes, heads=heads, n_layers=self.L).to(self.dev)
         else:
             raise ValueError("model must be 'sage' or 'gat'")
         try:     # one fused kernel per step (the for-each form is eight small launches, ~0.1 ms of GPU time)
             self.opt = torch.optim.Adam(self.model.parameters(), lr=lr, fused=True)
         except (RuntimeError, TypeError):
             self.opt = torch.optim.Adam(self.model.parameters(), lr=lr)
-        # rank_path=True forces the one-process-per-part code (collectives included) even for a single part:
-        # a way to run the RCCL calls on a one-GPU box
-        self.rank_path = (world > 1) if rank_path is None else bool(rank_path)
         self.comm = splitgnn.DistComm(device=self.dev) if self.rank_path else None
         self.overlap = overlap
         self.t_forward = self.t_slice = 0.0
@@ -86,7 +115,7 @@ class Trainer(object):
         else:
             # gather of owned input features (row v // P of the owner v % P), int32 indices, float4 row kernel
             _roctx.push("gather")
-            rows = deep.in_nodes if self.P == 1 else torch.div(deep.in_nodes, self.P, rounding_mode="floor")
+            rows = deep.in_nodes if self.P == 1 else self.local_row[deep.in_nodes.long()]
             x = aggr.gather_rows(self.feat, rows)
             _roctx.pop()
             t1 = time.perf_counter()
@@ -98,8 +127,8 @@ class Trainer(object):
                     logits = self.model.forward_rank(slices, x, self.rank, self.comm, overlap=self.overlap)
             else:
                 logits = self.model.forward_parts(slices, {0: x})[0]
-            seeds = top.out_nodes[top.owned_out_nodes.long()]  # the seeds this rank owns, frontier order
-            y = self.labels[(seeds // self.P).long()]
+            seeds = top.out_nodes[top.owned_out_nodes.long()].long()  # the seeds this rank owns, frontier order
+            y = self.labels[seeds if self.P == 1 else self.local_row[seeds].long()]
             # mean over the WHOLE minibatch: sum of local losses / global seed count
             loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / max(n_seeds, 1)
             _roctx.pop()
@@ -130,26 +159,25 @@ class Trainer(object):
         return loss.detach()
 
     def run(self, n_steps, first_batch=0):
-        """n_steps minibatches, S per engine round; the next round is sliced while this one trains."""
+        """n_steps minibatches starting at minibatch `first_batch` of the node order (wrapping around the epoch),
+        up to S per engine round; the next round is sliced while this one trains.  A round never crosses the end
+        of the epoch: the last round of an epoch holds the remaining n_batches % S minibatches, the last of them
+        possibly short -- every minibatch of the epoch is trained exactly once."""
         losses = []
-        rounds = (n_steps + self.S - 1) // self.S
-        per_epoch = max(1, self.n_batches // self.S)
+        plan = shard.round_plan(self.n_batches, self.S, first_batch, n_steps)
+        if not plan:
+            return losses
 
         def submit(r):
             torch.cuda.current_stream().synchronize()     # the slot's previous consumer has finished
-            first = ((first_batch // self.S + r) % per_epoch) * self.S
-            self.eng.submit_round(first, self.B, self.S, slot=r & 1)
+            self.eng.submit_round(plan[r][0], self.B, plan[r][1], slot=r & 1)
 
         submit(0)
-        done = 0
-        for r in range(rounds):
-            if r + 1 < rounds:
+        for r in range(len(plan)):
+            if r + 1 < len(plan):
                 submit(r + 1)
-            for s in range(self.S):
-                if done >= n_steps:
-                    break
+            for s in range(plan[r][1]):
                 losses.append(self._step(s, r & 1))
-                done += 1
         torch.cuda.synchronize()
         return [float(x) for x in losses]
 
@@ -163,11 +191,28 @@ class Trainer(object):
         self.eng.close()
 
 
-def synthetic_node_data(num_nodes, feat_dim, n_classes, seed=0):
-    """features f32 U[0,1) and random labels (datasets are not available offline)."""
-    rng = np.random.default_rng(seed)
-    feats = rng.random((num_nodes, feat_dim), dtype=np.float32)
-    labels = rng.integers(0, n_classes, size=num_nodes).astype(np.int64)
+def _mix64(x):
+    """splitmix64 finaliser on uint64 arrays: a counter-based generator, so any subset of rows can be produced
+    without the rows before it."""
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def synthetic_node_data(num_nodes, feat_dim, n_classes, seed=0, rows=None):
+    """features f32 U[0,1) and random labels (datasets are not available offline).  Every value is
+    a hash of (seed, node id, column), so `rows` (node ids) yields exactly the rows of the full matrix: each
+    rank generates only the nodes it owns."""
+    ids = np.arange(num_nodes, dtype=np.uint64) if rows is None else np.asarray(rows).astype(np.uint64)
+    base = np.uint64((int(seed) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
+    feats = np.empty((ids.shape[0], feat_dim), dtype=np.float32)
+    step = max(1, (1 << 24) // max(feat_dim, 1))
+    cols = np.arange(feat_dim, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        for lo in range(0, ids.shape[0], step):
+            h = _mix64((ids[lo:lo + step, None] * np.uint64(feat_dim) + cols + base) * np.uint64(0x9E3779B97F4A7C15))
+            feats[lo:lo + step] = (h >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))
+        labels = (_mix64((ids + base) * np.uint64(0xD6E8FEB86659FD93)) % np.uint64(n_classes)).astype(np.int64)
     return feats, labels
 
 
@@ -202,6 +247,10 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=1032)
     ap.add_argument("--dropout", type=float, default=0)
     ap.add_argument("--max-steps", type=int, default=0, help="(extra) stop an epoch after this many minibatches")
+    ap.add_argument("--partition", choices=("mod", "file"), default="mod",
+                    help="(extra) node ownership: `mod` = v %% world (pyfrontend.cpp:57), `file` = the L0 directory's "
+                         "partition_map_opt.bin (the METIS map of python/utils/sampler.py:64-134; its values must be "
+                         "< the number of ranks)")
     a = ap.parse_args(argv)
     from . import l0
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -214,27 +263,34 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group(backend=os.environ.get("CSLICER_DIST_BACKEND", "nccl"))
-    if a.graph == "synthetic":
-        indptr, indices = l0.synth_graph(200_000, 20.0, seed=0)
-        feats, labels = synthetic_node_data(indptr.shape[0] - 1, 128, 40, seed=0)
-        n_classes = 40
-    elif a.graph in l0.PRESETS:
-        n, d, fdim, n_classes = l0.PRESETS[a.graph]
+    workload, fdim = None, None
+    if a.graph == "synthetic" or a.graph in l0.PRESETS:
+        n, d, fdim, n_classes = (200_000, 20.0, 128, 40) if a.graph == "synthetic" else l0.PRESETS[a.graph]
         indptr, indices = l0.synth_graph(n, d, seed=0)
-        feats, labels = synthetic_node_data(n, fdim, n_classes, seed=0)
+        # every rank generates only the rows of the nodes it owns
+        feats = lambda own: synthetic_node_data(n, fdim, n_classes, seed=0, rows=own)[0]    # noqa: E731
+        labels = lambda own: synthetic_node_data(n, 1, n_classes, seed=0, rows=own)[1]      # noqa: E731
+        if a.partition == "file":
+            raise SystemExit("--partition file needs an L0 directory")
     else:
         indptr, indices, meta = l0.read_l0(a.graph, mmap=False)
-        n = meta["num_nodes"]
-        feats = np.fromfile(os.path.join(a.graph, "features.bin"), dtype=np.float32).reshape(n, meta["feature_dim"])
-        labels = np.fromfile(os.path.join(a.graph, "labels.bin"), dtype=np.int32).astype(np.int64)
+        n, fdim = meta["num_nodes"], meta["feature_dim"]
+        # memory-mapped: a rank touches only the rows it owns
+        fmap = np.memmap(os.path.join(a.graph, "features.bin"), dtype=np.float32, mode="r", shape=(n, fdim))
+        lmap = np.memmap(os.path.join(a.graph, "labels.bin"), dtype=np.int32, mode="r", shape=(n,))
+        feats = lambda own: np.asarray(fmap[own])                                            # noqa: E731
+        labels = lambda own: np.asarray(lmap[own]).astype(np.int64)                          # noqa: E731
         n_classes = meta["num_classes"]
+        if a.partition == "file":
+            workload = np.fromfile(os.path.join(a.graph, "partition_map_opt.bin"), dtype=np.int32)
     fan = tuple(int(x) for x in a.fan_out.split(","))[::-1]          # engine order: layer 0 = hop from the seeds
     if len(fan) != a.num_layers:
         fan = fan[:a.num_layers] if len(fan) > a.num_layers else fan
     kind = "gat" if a.model_name == "gat" else "sage"
     hidden = a.num_hidden // a.num_heads if kind == "gat" else a.num_hidden
     tr = Trainer(indptr, indices, feats, labels, n_classes, rank=rank, world=world, fanouts=fan, batch=a.batch_size,
-                 streams=8, hidden=max(4, hidden // 4 * 4), lr=a.lr, device=local, dist=dist, model=kind, heads=a.num_heads)
+                 streams=8, hidden=max(4, hidden // 4 * 4), lr=a.lr, device=local, dist=dist, model=kind, heads=a.num_heads,
+                 workload=workload, feat_dim=fdim)
     n = indptr.shape[0] - 1
     for epoch in range(a.num_epochs):
         tr.set_nodes(np.random.default_rng(epoch).permutation(n))

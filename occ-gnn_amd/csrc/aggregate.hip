@@ -383,17 +383,23 @@ __global__ __launch_bounds__(BLK) void k_sage_cat_bwd(const int* __restrict__ in
 // the column sums of `out` (the bias gradient): ReLU backward, the row padding of the GEMM operand and the bias
 // reduction in one pass over the gradient.  Two stages, no atomics and nothing to pre-zero: every block leaves the
 // column sums of its RB_ROWS rows in partial[block][H], k_colsum_finish adds the blocks up.
-constexpr int RB_ROWS = 128;  // rows per block
 constexpr int RB_U = 4;       // rows a thread has in flight
+// rows per block: 128, or more when that keeps the number of blocks (= partial sums per column) at <= 512
+__host__ __device__ inline long long rb_rows(long long n_pad) {
+  long long r = 128;
+  while ((n_pad + r - 1) / r > 512) r *= 2;
+  return r;
+}
 template <int G>
 __global__ __launch_bounds__(BLK) void k_relu_bwd_colsum(const float* __restrict__ g, long long ldg,
                                                          const float* __restrict__ y, long long ldy, long long n,
                                                          long long n_pad, float* __restrict__ out, long long ldo,
-                                                         float* __restrict__ partial, int H, int vec) {
+                                                         float* __restrict__ partial, int H, int vec,
+                                                         long long rows_per_block) {
   constexpr int RPB = BLK / G;  // row groups of the block
   const int lane = threadIdx.x % G, sub = threadIdx.x / G;
-  const long long r0 = (long long)blockIdx.x * RB_ROWS;
-  const long long r_end = r0 + RB_ROWS < n_pad ? r0 + RB_ROWS : n_pad;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r_end = r0 + rows_per_block < n_pad ? r0 + rows_per_block : n_pad;
   __shared__ float s_sum[BLK * 4];
   // (the column loop is block-uniform: every thread reaches the barriers)
   for (int c0 = 0; c0 < H; c0 += G * 4) {
@@ -456,14 +462,25 @@ __global__ __launch_bounds__(BLK) void k_relu_bwd_colsum(const float* __restrict
     }
   }
 }
-// out[c] = sum over the blocks of partial[block][c]: 4 x 64 threads per 64 columns, the four groups split the blocks
+// out[c] = sum over the blocks of partial[block][c]: 4 x 64 threads per 64 columns, the four groups split the
+// blocks; eight independent loads in flight per thread
 __global__ __launch_bounds__(BLK) void k_colsum_finish(const float* __restrict__ partial, long long nblk, int H,
                                                        float* __restrict__ out) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   __shared__ float s_q[BLK];
   float acc = 0.f;
-  if (c < H)
-    for (long long b = q; b < nblk; b += BLK / 64) acc += partial[b * H + c];
+  if (c < H) {
+    constexpr int Q = BLK / 64, U = 8;
+    long long b = q;
+    for (; b + (U - 1) * Q < nblk; b += U * Q) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = partial[(b + u * Q) * H + c];
+#pragma unroll
+      for (int u = 0; u < U; u++) acc += v[u];
+    }
+    for (; b < nblk; b += Q) acc += partial[b * H + c];
+  }
   s_q[threadIdx.x] = acc;
   __syncthreads();
   if (q == 0 && c < H) out[c] = s_q[threadIdx.x] + s_q[threadIdx.x + 64] + s_q[threadIdx.x + 128] + s_q[threadIdx.x + 192];
@@ -642,14 +659,16 @@ int csl_sage_cat_bwd_f32(const int32_t* indptr, const int32_t* indices, const in
 }
 
 int64_t csl_relu_bwd_colsum_scratch(int64_t n_pad, int32_t H) {
-  return ((n_pad + RB_ROWS - 1) / RB_ROWS) * (int64_t)(H > 0 ? H : 0);
+  const long long rpb = rb_rows(n_pad);
+  return ((n_pad + rpb - 1) / rpb) * (int64_t)(H > 0 ? H : 0);
 }
 
 int csl_relu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t n, int64_t n_pad,
                             float* out, int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream) {
   if (n < 0 || n_pad < n || H < 1 || !colsum) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  const long long blocks = (n_pad + RB_ROWS - 1) / RB_ROWS;
+  const long long rpb = rb_rows(n_pad);
+  const long long blocks = (n_pad + rpb - 1) / rpb;
   if (blocks > 0) {
     if (!scratch || !out || ldo < H || (n > 0 && (!g || ldg < H)) || (y && ldy < H)) return CSL_E_INVALID;
     const int G = group_for(H);
@@ -657,7 +676,7 @@ int csl_relu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t
                     aligned16(out) && (!y || aligned16(y));
 #define LAUNCH_RBC(GG)                                                                                         \
   hipLaunchKernelGGL(k_relu_bwd_colsum<GG>, dim3((unsigned)blocks), dim3(BLK), 0, st, g, (long long)ldg, y,    \
-                     (long long)ldy, (long long)n, (long long)n_pad, out, (long long)ldo, scratch, (int)H, vec)
+                     (long long)ldy, (long long)n, (long long)n_pad, out, (long long)ldo, scratch, (int)H, vec, rpb)
     switch (G) {
       case 1: case 2: case 4: LAUNCH_RBC(4); break;
       case 8: LAUNCH_RBC(8); break;

@@ -143,6 +143,7 @@ struct LArgs {
   unsigned long long wmagic;  // ceil(2^40 / W): exact c / W for c < 2^31, W < 512
   uint32_t S;
   uint32_t tpb;               // frontier tiles per k_sample block
+  uint32_t pmask;             // bit g: the lists of part g are written (csl_config.part_mask; all ones = every part)
   uint32_t last;              // 1 on the final layer (no next frontier to prepare)
   // repeated seed ids (layer 0 only; bipartite.cpp:3-17 on a batch with duplicates): see k_dupseeds
   uint32_t* dupflag;          // [S] != 0: the stream's minibatch holds a seed id more than once
@@ -1118,7 +1119,7 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
         }
       }
 #ifndef CSL_ABLATE_EMIT_IN
-      if (fe) {
+      if (fe && ((a.pmask >> g) & 1u)) {
         const uint32_t p = s_run[b][1 + g] + rE + BYTESUM(s_wc[b][1 + g] & below);  // local index inside slice g's in_nodes
         in_list[s_mo[0][g] + p] = (int)val;
         // DuplicateRemover::replace's lookup value (mask[v]-1): read back by k_selfin for candidates whose
@@ -1184,10 +1185,10 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
     for (uint32_t g = 0; g < CSL_MAX_PARTS; g++) {
       if (g < P && ((hb >> g) & 1u)) {
         const uint32_t p = RANK(0, g) + s_tb[0 * P + g];  // local index inside slice g's out_nodes
+        if (g == to) outrank_to = p;
+        if (!((a.pmask >> g) & 1u)) continue;  // slice g is not materialised here
         ar[a.list_base[CSL_OUT_NODES] + s_mo[1][g] + p] = (int)v;
-        if (g == to) {
-          outrank_to = p;
-        } else if (!a.graph) {
+        if (g != to && !a.graph) {
           const uint32_t q = RANK(4, g) + s_tb[4 * P + g];
           ar[a.list_base[CSL_FROM_IDS] + s_mo[5][g] + q] = (int)p;
         }
@@ -1195,17 +1196,18 @@ __global__ __launch_bounds__(TN) void k_emit(LArgs a) {
     }
     const uint32_t tsh = 8u * (to & 3u);
 #define RANK_TO(k) (((to_hi ? wd[k][1] : wd[k][0]) >> tsh) & 0xFFu)
+    const bool mine = (a.pmask >> to) & 1u;  // the node's own slice is materialised here
     {
       const uint32_t q = RANK_TO(2) + s_tb[2 * P + to];
       const uint32_t pos = s_mo[3][to] + q;
-      ar[a.list_base[CSL_SELF_IDS_OUT] + pos] = outrank_to;
-      a.selfpos[s * a.fcap + i] = pos;  // k_selfin fills self_ids_in at the same place
+      if (mine) ar[a.list_base[CSL_SELF_IDS_OUT] + pos] = outrank_to;
+      a.selfpos[s * a.fcap + i] = mine ? pos : UNSET;  // k_selfin fills self_ids_in at the same place
     }
-    if (outrank_to >= 0) {
+    if (outrank_to >= 0 && mine) {
       const uint32_t q = RANK_TO(1) + s_tb[1 * P + to];
       ar[a.list_base[CSL_OWNED_OUT_NODES] + s_mo[2][to] + q] = outrank_to;
     }
-    if (!a.graph && oth != 0) {
+    if (!a.graph && oth != 0 && mine) {
       const uint32_t q = RANK_TO(3) + s_tb[3 * P + to];
       ar[a.list_base[CSL_TO_IDS] + s_mo[4][to] + q] = outrank_to;
     }
@@ -1436,7 +1438,7 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
       outrank[g] = p + TB(K_OUT(P, g));
       rs[g] = q + TB(K_ECNT(P, g));  // first index of this node's row in slice g's indices
       deg += ec[g];
-      if ((hb >> g) & 1u)
+      if (((hb >> g) & 1u) && ((a.pmask >> g) & 1u))
         ar[a.list_base[CSL_INDPTR] + m.off[CSL_INDPTR][g] + outrank[g] + 1] = (int)(rs[g] + ec[g]);
       if (i == 0) ar[a.list_base[CSL_INDPTR] + m.off[CSL_INDPTR][g]] = 0;
     }
@@ -1447,12 +1449,14 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
       uint32_t q = r_pair[g];
       for (uint32_t ww = 0; ww < w; ww++) q += s_wp[ww][g * CSL_MAX_PARTS + to];
       q += TB(K_PAIR(P, g, to));
-      ar[a.list_base[CSL_FROM_IDS] + m.off[CSL_FROM_IDS][g] + m.pair_off[0][g][to] + q] = (int)outrank[g];
-      ar[a.list_base[CSL_TO_IDS] + m.off[CSL_TO_IDS][to] + m.pair_off[1][to][g] + q] = (int)outrank[to];
+      if ((a.pmask >> g) & 1u)
+        ar[a.list_base[CSL_FROM_IDS] + m.off[CSL_FROM_IDS][g] + m.pair_off[0][g][to] + q] = (int)outrank[g];
+      if ((a.pmask >> to) & 1u)
+        ar[a.list_base[CSL_TO_IDS] + m.off[CSL_TO_IDS][to] + m.pair_off[1][to][g] + q] = (int)outrank[to];
     }
   }
   // mean divisor, next to owned_out_nodes (same order as self_ids_*)
-  {
+  if ((a.pmask >> to) & 1u) {
     const uint32_t q = a.selfpos[s * a.fcap + i] - m.off[CSL_SELF_IDS_OUT][to];
     ar[a.list_base[CSL_OWNED_DEGREE] + m.off[CSL_OWNED_DEGREE][to] + q] = (int)deg;
   }
@@ -1462,6 +1466,7 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
     const uint32_t val = a.cand[cb + slot];
     if (val == UNSET) continue;
     const uint32_t g = owner(a, val);
+    if (!((a.pmask >> g) & 1u)) continue;  // the edge lives in a slice that is not materialised here
     const uint32_t rank = a.crank[(size_t)s * a.ccap + a.srcpos[cb + slot]];
     uint32_t pos = 0;
 #pragma unroll
@@ -2012,6 +2017,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.wmagic = ((1ull << 40) + a.W - 1) / a.W;
     a.S = (uint32_t)S;
     a.last = l == L - 1 ? 1u : 0u;
+    a.pmask = e->cfg.part_mask ? e->cfg.part_mask : 0xFFFFFFFFu;
     a.graph = e->cfg.mode == CSL_MODE_GRAPH ? 1u : 0u;
     a.ecnt = e->ecnt ? e->ecnt + sF * e->P : nullptr;
     a.srcpos = e->srcpos ? e->srcpos + sC : nullptr;
@@ -2366,6 +2372,7 @@ int csl_create(const csl_config* cfg, csl_engine** out) {
   if (cfg->n_slots < 1 || cfg->n_slots > 16) return fail(CSL_E_INVALID, "n_slots must be 1..16");
   if (cfg->max_batch < 1) return fail(CSL_E_INVALID, "max_batch must be >= 1");
   if (cfg->mode != CSL_MODE_STRICT && cfg->mode != CSL_MODE_GRAPH) return fail(CSL_E_INVALID, "unknown mode %d", cfg->mode);
+  if (cfg->part_mask >> cfg->n_parts) return fail(CSL_E_INVALID, "part_mask 0x%x names parts beyond n_parts", cfg->part_mask);
   if (!cfg->indptr || (!cfg->indices && cfg->num_edges > 0)) return fail(CSL_E_INVALID, "graph arrays missing");
   // the reference keeps ids in `int` (bipartite.h:55): node ids are only defined below 2^31.  Row offsets:
   // the reference's `int offset` (slicer.cpp:9) wraps at 2^31 edges, i.e. its behaviour is undefined beyond;

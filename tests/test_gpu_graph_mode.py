@@ -151,3 +151,38 @@ def test_strict_and_graph_share_sampling(abi):
                 np.testing.assert_array_equal(b["out_nodes"][keep], a["out_nodes"])
     es.close()
     eg.close()
+
+
+@pytest.mark.parametrize("mode", ["graph", "strict"])
+def test_part_mask_materialises_only_the_asked_slices(mode):
+    """csl_config.part_mask (one process per part asks for its own slice only): the lists of the parts in the
+    mask, every size/offset in the meta, the frontiers and the draw counts equal the unmasked engine's."""
+    from cslicer import _abi, l0
+    indptr, indices = l0.synth_graph(5000, 22.0, seed=4)
+    rng = np.random.default_rng(6)
+    wl = rng.integers(0, 4, size=5000).astype(np.int32)
+    perm = rng.permutation(5000)
+    md = _abi.MODE_GRAPH if mode == "graph" else _abi.MODE_STRICT
+    full = _abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 5, 5), max_batch=300, n_streams=2, mode=md, workload=wl)
+    full.set_nodes(perm)
+    full.submit_round(0, 300, 2)
+    for mask in (1 << 2, (1 << 0) | (1 << 3)):
+        e = _abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 5, 5), max_batch=300, n_streams=2, mode=md,
+                        workload=wl, part_mask=mask)
+        e.set_nodes(perm)
+        e.submit_round(0, 300, 2)
+        for s in range(2):
+            m0, m1 = full.meta(s), e.meta(s)
+            assert bytes(m0) == bytes(m1)                      # sizes, offsets, rng positions: all of it
+            for l in range(3):
+                np.testing.assert_array_equal(full.copy_frontier(l + 1, s), e.copy_frontier(l + 1, s))
+                for g in range(4):
+                    if not (mask >> g) & 1:
+                        continue
+                    for k in range(_abi.NUM_LISTS):
+                        np.testing.assert_array_equal(full.copy_list(l, k, g, s, meta=m0), e.copy_list(l, k, g, s, meta=m1),
+                                                      err_msg="mask %x layer %d part %d kind %d" % (mask, l, g, k))
+        e.close()
+    full.close()
+    with pytest.raises(_abi.CslError):
+        _abi.Engine(indptr, indices, n_parts=4, part_mask=1 << 5)

@@ -45,7 +45,12 @@ def _free_port():
     return p
 
 
-def _rank_main(rank, world, port, q, overlap=False, kind="sage"):
+def _table(n, world, seed=11):
+    """A node -> part table that is NOT v % world (the METIS-map use case)."""
+    return np.random.default_rng(seed).integers(0, world, size=n).astype(np.int32)
+
+
+def _rank_main(rank, world, port, q, overlap=False, kind="sage", table=False):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "occ-gnn_amd"))
@@ -55,18 +60,30 @@ def _rank_main(rank, world, port, q, overlap=False, kind="sage"):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        _rank_body(rank, world, q, overlap, kind, dist)
+        _rank_body(rank, world, q, overlap, kind, dist, table)
     except Exception as ex:      # the parent must hear about it instead of waiting for the queue
         q.put((rank, "error: " + repr(ex), None))
         raise
 
 
-def _rank_body(rank, world, q, overlap, kind, dist):
+def _rank_body(rank, world, q, overlap, kind, dist, table=False):
     from cslicer.train import Trainer
-    from test_gpu_train import _task
+    from test_gpu_train import _table, _task
     indptr, indices, feats, labels, perm = _task()
-    t = Trainer(indptr, indices, feats, labels, 5, rank=rank, world=world, fanouts=(10, 5), batch=128, streams=2,
-                hidden=16, lr=1e-2, dist=dist, overlap=overlap, model=kind, heads=2)
+    wl = _table(indptr.shape[0] - 1, world) if table else None
+    # with a table the rank is handed loaders, not the full arrays: it must ask for its own rows only
+    asked = []
+
+    def load(a):
+        def f(own):
+            asked.append(np.asarray(own))
+            return a[own]
+        return f
+    t = Trainer(indptr, indices, load(feats) if table else feats, load(labels) if table else labels, 5, rank=rank,
+                world=world, fanouts=(10, 5), batch=128, streams=2, hidden=16, lr=1e-2, dist=dist, overlap=overlap,
+                model=kind, heads=2, workload=wl, feat_dim=feats.shape[1])
+    if table:
+        assert len(asked) == 2 and all(bool((wl[o] == rank).all()) and len(o) == int((wl == rank).sum()) for o in asked)
     t.set_nodes(perm)
     losses = t.run(4)
     tl = torch.tensor(losses, dtype=torch.float64)
@@ -78,16 +95,17 @@ def _rank_body(rank, world, q, overlap, kind, dist):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,kind", [(False, "sage"), (True, "sage"), (False, "gat")],
-                         ids=["sequential", "side-stream-overlap", "gat"])
-def test_two_ranks_match_single_process_two_parts(overlap, kind):
+@pytest.mark.parametrize("overlap,kind,table", [(False, "sage", False), (True, "sage", False), (False, "gat", False),
+                                                (False, "sage", True), (True, "sage", True)],
+                         ids=["sequential", "side-stream-overlap", "gat", "partition-table", "partition-table-overlap"])
+def test_two_ranks_match_single_process_two_parts(overlap, kind, table):
     import torch.multiprocessing as mp
     from cslicer import _abi, splitgnn
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, overlap, kind)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q, overlap, kind, table)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda x: x[0])
@@ -100,7 +118,7 @@ def test_two_ranks_match_single_process_two_parts(overlap, kind):
     indptr, indices, feats, labels, perm = _task()
     dev = torch.device("cuda", 0)
     eng = _abi.Engine(indptr, indices, n_parts=2, fanouts=(10, 5), max_batch=128, n_streams=2, n_slots=2,
-                      mode=_abi.MODE_GRAPH)
+                      mode=_abi.MODE_GRAPH, workload=_table(indptr.shape[0] - 1, 2) if table else None)
     eng.set_nodes(perm)
     torch.manual_seed(0)
     if kind == "gat":

@@ -77,3 +77,19 @@ def test_epoch_plan_single_rank_and_tail():
     plan3 = shard.epoch_plan(1000, 100, 4, 3)
     assert [r for r, _, _ in plan3] == [0, 1, 2]
     assert shard.round_of(3, 1, 4, 5) == (3 * 4 + 1) % 5
+
+
+def test_round_plan_covers_every_minibatch_once():
+    """Trainer.run's rounds (cslicer/shard.py::round_plan): 194 minibatches with 8 streams = 24 full rounds + one
+    round of 2; a second epoch starts over at minibatch 0; an unaligned start works too."""
+    from cslicer import shard
+    plan = shard.round_plan(194, 8, 0, 194)
+    assert len(plan) == 25 and plan[-1] == (192, 2) and all(k == 8 for _, k in plan[:-1])
+    seen = [b + j for b, k in plan for j in range(k)]
+    assert seen == list(range(194))
+    two = shard.round_plan(194, 8, 0, 2 * 194)
+    seen = [b + j for b, k in two for j in range(k)]
+    assert seen == list(range(194)) * 2
+    part = shard.round_plan(10, 4, 7, 9)          # 7 8 9 | 0 1 2 3 | 4 5
+    assert part == [(7, 3), (0, 4), (4, 2)]
+    assert shard.round_plan(0, 4, 0, 5) == [] and shard.round_plan(5, 4, 0, 0) == []
