@@ -105,6 +105,13 @@ int csl_softmax_ce_f32(const float* logits, int64_t ldl, int64_t n, int32_t C, c
                        const int64_t* labels, float scale, float* loss, float* grad, int64_t ldgr, float* scratch,
                        void* stream);
 
+/* torch.optim.Adam's update (python/train.py:83; no weight decay, no amsgrad) for up to 24 parameter tensors in one
+ * launch.  params / grads / exp_avg / exp_avg_sq: HOST arrays of `count` device pointers, numel[t] elements each;
+ * step = 1 for the first update (bias corrections 1 - beta^step are computed on the host). */
+int csl_adam_f32(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
+                 int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ from . import _abi
 SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_scatter_add_rows_f32", "csl_div_rows_f32", "csl_gat_fwd_f32", "csl_gat_bwd_f32",
            "csl_sage_cat_f32", "csl_sage_cat_bwd_f32", "csl_relu_bwd_colsum_f32", "csl_softmax_ce_f32",
-           "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch"]
+           "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch", "csl_adam_f32"]
 _ready = False
 
 
@@ -39,6 +39,7 @@ def _lib():
         L.csl_softmax_ce_f32.argtypes = [vp, i64, i64, i32, vp, vp, vp, f32, vp, vp, i64, vp, vp]
         L.csl_softmax_ce_scratch.argtypes = [i64]
         L.csl_softmax_ce_scratch.restype = i64
+        L.csl_adam_f32.argtypes = [i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, vp]
         _ready = True
     return L
 
@@ -315,3 +316,44 @@ def attention_gather(indptr, indices, u_in, v_in, n_rows):
     (u, v) of u_in[u] * v_in[v] (DGL u_mul_v + sum).  v_in[v] does not depend on u, so this is the
     sum-aggregate scaled row-wise: one SpMM launch plus an elementwise product."""
     return SpmmSum.apply(u_in, indptr, indices, n_rows) * v_in
+
+
+class Adam(object):
+    """torch.optim.Adam's update (lr, betas, eps; no weight decay, no amsgrad: what python/train.py:83 uses) for a
+    handful of fp32 CUDA parameters in ONE HIP launch per step (csl_adam_f32).  Same interface as far as the
+    trainer needs it: zero_grad(set_to_none=True), step(); the moments live in `state`."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params or len(self.params) > 24:
+            raise ValueError("1..24 parameter tensors")
+        for p in self.params:
+            if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                raise TypeError("contiguous float32 CUDA parameters expected")
+        self.lr, self.betas, self.eps, self.t = float(lr), (float(betas[0]), float(betas[1])), float(eps), 0
+        self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in self.params]
+        n = len(self.params)
+        self._p = (C.c_void_p * n)(*[p.data_ptr() for p in self.params])
+        self._m = (C.c_void_p * n)(*[m.data_ptr() for m, _ in self.state])
+        self._v = (C.c_void_p * n)(*[v.data_ptr() for _, v in self.state])
+        self._n = (C.c_int64 * n)(*[p.numel() for p in self.params])
+        self._g = (C.c_void_p * n)()
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def step(self):
+        for k, p in enumerate(self.params):
+            g = p.grad
+            if g is None:
+                raise RuntimeError("parameter %d has no gradient" % k)
+            if not g.is_contiguous():
+                g = p.grad = g.contiguous()
+            self._g[k] = g.data_ptr()
+        self.t += 1
+        _chk(_lib().csl_adam_f32(len(self.params), self._p, self._g, self._m, self._v, self._n, self.lr,
+                                 self.betas[0], self.betas[1], self.eps, self.t, _stream()), "csl_adam_f32")

@@ -77,6 +77,37 @@ def synth_graph(num_nodes, mean_deg, seed=0, alpha=1.5, degrees=None, sort_rows=
     return indptr, cols
 
 
+def synth_graph_big(num_nodes, mean_deg, seed=0, alpha=1.5, chunk=4_000_000):
+    """synth_graph for graphs with 10^9 edges (papers-like): same degree law and uniform neighbours, rows NOT
+    sorted, built node-chunk by node-chunk so that only the result itself (indptr + indices) is ever held;
+    the degree scale is tuned on the first two million draws instead of all of them."""
+    rng = np.random.default_rng(seed)
+    cap = int(min(num_nodes - 1, 20_000))
+    x = rng.pareto(alpha, num_nodes)
+    sub = x[:2_000_000]
+    lo, hi = 0.0, float(max(mean_deg, 1.0)) * 64.0
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if np.minimum(np.floor(sub * mid + 1), cap).mean() < mean_deg:
+            lo = mid
+        else:
+            hi = mid
+    deg = np.minimum(np.floor(x * (0.5 * (lo + hi)) + 1), cap).astype(np.int64)
+    del x
+    indptr = np.zeros(num_nodes + 1, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    cols = np.empty(int(indptr[-1]), dtype=np.int64)
+    for a in range(0, num_nodes, chunk):
+        b = min(num_nodes, a + chunk)
+        e0, e1 = int(indptr[a]), int(indptr[b])
+        c = rng.integers(0, num_nodes, size=e1 - e0, dtype=np.int64)
+        rows = np.repeat(np.arange(a, b, dtype=np.int64), deg[a:b])
+        hit = c == rows                                    # no self loops (convert_dgl_dataset.py:45)
+        c[hit] = (c[hit] + 1) % num_nodes
+        cols[e0:e1] = c
+    return indptr, cols
+
+
 def synth_preset(name, seed=0):
     n, d, _, _ = PRESETS[name]
     return synth_graph(n, d, seed=seed)

@@ -10,6 +10,7 @@
 // 64/G rows share a wave so short feature rows still fill every lane.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 
 #include "cslicer_aggr.h"
@@ -384,10 +385,10 @@ __global__ __launch_bounds__(BLK) void k_sage_cat_bwd(const int* __restrict__ in
 // reduction in one pass over the gradient.  Two stages, no atomics and nothing to pre-zero: every block leaves the
 // column sums of its RB_ROWS rows in partial[block][H], k_colsum_finish adds the blocks up.
 constexpr int RB_U = 4;       // rows a thread has in flight
-// rows per block: 128, or more when that keeps the number of blocks (= partial sums per column) at <= 512
+// rows per block: 128 (enough blocks in flight to cover the memory latency), more only beyond 2048 blocks
 __host__ __device__ inline long long rb_rows(long long n_pad) {
   long long r = 128;
-  while ((n_pad + r - 1) / r > 512) r *= 2;
+  while ((n_pad + r - 1) / r > 2048) r *= 2;
   return r;
 }
 template <int G>
@@ -515,6 +516,39 @@ __global__ __launch_bounds__(BLK) void k_softmax_ce(const float* __restrict__ lo
   if (lane == 0) s_l[w] = mine;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = s_l[0] + s_l[1] + s_l[2] + s_l[3];
+}
+
+// ---- Adam (python/train.py:83 torch.optim.Adam, no weight decay, no amsgrad) over every parameter tensor of the
+// model in ONE launch: the model has six small tensors, the library's for-each form is 1-8 launches of 20-40 us.
+//   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+constexpr int ADAM_MAX = 24;
+struct AdamArgs {
+  float* p[ADAM_MAX];
+  const float* g[ADAM_MAX];
+  float* m[ADAM_MAX];
+  float* v[ADAM_MAX];
+  long long first_block[ADAM_MAX + 1];  // blocks of ADAM_CHUNK elements, tensors back to back
+  long long n[ADAM_MAX];
+  int count;
+};
+constexpr int ADAM_CHUNK = 1024;
+__global__ __launch_bounds__(BLK) void k_adam(AdamArgs a, float b1, float b2, float step_size, float inv_sqrt_bc2,
+                                              float eps) {
+  int t = 0;
+  while (t + 1 < a.count && (long long)blockIdx.x >= a.first_block[t + 1]) t++;
+  const long long base = ((long long)blockIdx.x - a.first_block[t]) * ADAM_CHUNK;
+  float* __restrict__ p = a.p[t];
+  const float* __restrict__ g = a.g[t];
+  float* __restrict__ m = a.m[t];
+  float* __restrict__ v = a.v[t];
+  for (long long i = base + threadIdx.x; i < base + ADAM_CHUNK && i < a.n[t]; i += BLK) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
 }
 
 int group_for(int H) {
@@ -704,6 +738,33 @@ int csl_softmax_ce_f32(const float* logits, int64_t ldl, int64_t n, int32_t C, c
                        (int)C, ids, rowmap, (const long long*)labels, scale, scratch, grad, (long long)ldgr);
   }
   hipLaunchKernelGGL(k_colsum_finish, dim3(1), dim3(BLK), 0, st, scratch, blocks, 1, loss);
+  return done();
+}
+
+int csl_adam_f32(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
+                 int64_t step, void* stream) {
+  if (count < 0 || count > ADAM_MAX || step < 1) return CSL_E_INVALID;
+  if (count == 0) return CSL_OK;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel) return CSL_E_INVALID;
+  AdamArgs a;
+  long long blocks = 0;
+  for (int t = 0; t < count; t++) {
+    if (numel[t] < 0 || (numel[t] > 0 && (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t]))) return CSL_E_INVALID;
+    a.p[t] = params[t];
+    a.g[t] = grads[t];
+    a.m[t] = exp_avg[t];
+    a.v[t] = exp_avg_sq[t];
+    a.n[t] = numel[t];
+    a.first_block[t] = blocks;
+    blocks += (numel[t] + ADAM_CHUNK - 1) / ADAM_CHUNK;
+  }
+  a.first_block[count] = blocks;
+  a.count = count;
+  if (blocks == 0) return CSL_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(BLK), 0, (hipStream_t)stream, a, beta1, beta2,
+                     (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps);
   return done();
 }
 

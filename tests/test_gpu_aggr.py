@@ -360,3 +360,21 @@ def test_fused_local_model_reads_the_feature_table(mods):
     for a_, b_ in zip(grads[0][1], grads[1][1]):
         torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-5)
     eng.close()
+
+
+def test_adam_matches_torch(mods):
+    """aggr.Adam (csl_adam_f32, one launch for all tensors) against torch.optim.Adam over 20 steps."""
+    _, aggr, _ = mods
+    torch.manual_seed(5)
+    shapes = [(256, 200), (256,), (47, 512), (47,), (3,), (1025, 3)]
+    pa = [torch.randn(s, device="cuda").requires_grad_() for s in shapes]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    oa, ob = aggr.Adam(pa, lr=3e-3), torch.optim.Adam(pb, lr=3e-3)
+    for _ in range(20):
+        for a_, b_ in zip(pa, pb):
+            g = torch.randn_like(a_)
+            a_.grad, b_.grad = g.clone(), g.clone()
+        oa.step()
+        ob.step()
+    for a_, b_ in zip(pa, pb):
+        torch.testing.assert_close(a_.detach(), b_.detach(), rtol=1e-5, atol=1e-6)

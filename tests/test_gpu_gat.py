@@ -127,3 +127,83 @@ def test_split_parallel_gat_matches_dense_reference(mods, P, fan, heads):
         ids = slices[L - 1][g].in_nodes.cpu().long()
         torch.testing.assert_close(x[g].grad.cpu(), fin.grad[ids], rtol=1e-4, atol=1e-5)
     eng.close()
+
+
+def _dense_gat_vectorised(model, trav, feats):
+    """The unsplit definition on the same sampled computation graph with index ops (any device), for sizes the
+    python-loop reference above cannot reach."""
+    L = len(trav["nbr_counts"])
+    dev = feats.device
+    h = feats
+    for k, conv in enumerate(model.convs):
+        l = L - 1 - k
+        fr = torch.as_tensor(np.asarray(trav["frontier"][l]), device=dev).long()
+        counts = torch.as_tensor(np.asarray(trav["nbr_counts"][l]), device=dev).long()
+        flat = torch.as_tensor(np.asarray(trav["nbr_flat"][l]), device=dev).long()
+        owner = torch.repeat_interleave(fr, counts)                 # destination of every entry of the stream
+        keep = flat != owner                                        # drops the leading self entry and sampled self loops
+        dst, src = owner[keep], flat[keep]
+        z = h @ conv.fc.weight.t()
+        zv = z.view(-1, conv.H, conv.D)
+        el, er = (zv * conv.attn_l).sum(-1), (zv * conv.attn_r).sum(-1)
+        score = torch.nn.functional.leaky_relu(el[src] + er[dst], conv.slope)            # [E, H]
+        n_all = h.shape[0]
+        m = torch.full((n_all, conv.H), -1e30, device=dev).scatter_reduce(
+            0, dst[:, None].expand(-1, conv.H), score.detach(), "amax", include_self=True)
+        p = torch.exp(score - m[dst])
+        ssum = torch.zeros((n_all, conv.H), device=dev).index_add(0, dst, p)
+        num = torch.zeros((n_all, conv.H, conv.D), device=dev).index_add(0, dst, p[:, :, None] * zv[src])
+        out = (num / ssum.clamp_min(1e-30)[:, :, None]).reshape(n_all, -1) + conv.bias
+        new = torch.zeros_like(out).index_copy(0, fr, out[fr])
+        if k + 1 < len(model.convs):
+            h = torch.nn.functional.elu(new)
+        else:
+            h = new.view(-1, model.heads, conv.D).mean(1)[:, :model.n_classes]
+    return h
+
+
+def test_gat_config5_shape_eight_parts(mods):
+    """BASELINE configs[4] shape: 3-layer GAT, 8 heads x 32, fanout 10/10/10, batch 1024, EIGHT parts (all in this
+    process; products-like degrees on a 400k-node graph so that the dense reference fits), against the unsplit
+    definition computed with torch index ops in fp32 on the same sampled graph.  ~10^6 sampled edges and
+    frontiers of ~10^5 nodes: sums of that length differ by summation order, so the tolerances are 1e-4 relative
+    for the outputs (1e-5 holds for the single aggregation kernel, tested above) and 2e-3 for the gradients."""
+    abi, aggr, sg = mods
+    from cslicer import l0
+    from oracle import oracle as orc
+    torch.manual_seed(2)
+    n, F0, hidden, classes, B, P, heads, fan = 400_000, 100, 32, 47, 1024, 8, 8, (10, 10, 10)
+    indptr, indices = l0.synth_graph(n, 50.5, seed=0)
+    seeds = np.random.default_rng(4).permutation(n)[:B]
+    eng = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, mode=abi.MODE_GRAPH)
+    eng.submit_seeds([seeds])
+    slices = sg.slices_of(eng)
+    L = len(fan)
+    feats = torch.randn(n, F0, device="cuda")
+    model = sg.DistGATModel(F0, hidden, classes, heads=heads, n_layers=L).cuda()
+    with torch.no_grad():
+        for conv in model.convs:
+            conv.bias.normal_(0, 0.1)
+    x = {g: feats[slices[L - 1][g].in_nodes.long()].clone().requires_grad_() for g in range(P)}
+    out = model.forward_parts(slices, x)
+    assert sum(out[g].shape[0] for g in range(P)) == B
+    w = torch.randn(n, classes, device="cuda")
+    seeds_t = torch.from_numpy(seeds).cuda()
+    sum((out[g] * w[seeds_t[seeds_t % P == g]]).sum() for g in range(P)).backward()
+    got_grads = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    trav = orc.Oracle(indptr, indices, n_parts=P, fanouts=fan).sample(seeds)
+    fin = feats.clone().requires_grad_()
+    ref = _dense_gat_vectorised(model, trav, fin)
+    for g in range(P):
+        own = seeds_t[seeds_t % P == g]
+        torch.testing.assert_close(out[g].detach(), ref[own].detach(), rtol=1e-4, atol=1e-5)
+    (ref[seeds_t] * w[seeds_t]).sum().backward()
+    for (name, p_), gg in zip(model.named_parameters(), got_grads):
+        scale = float(p_.grad.abs().max())
+        torch.testing.assert_close(gg, p_.grad, rtol=2e-3, atol=2e-4 * max(scale, 1e-3), msg=lambda m_: "grad " + name + ": " + m_)
+    for g in range(P):
+        ids = slices[L - 1][g].in_nodes.long()
+        scale = float(fin.grad[ids].abs().max())
+        torch.testing.assert_close(x[g].grad, fin.grad[ids], rtol=2e-3, atol=2e-4 * max(scale, 1e-3))
+    eng.close()

@@ -510,3 +510,33 @@ def test_reference_digest_parity_at_realistic_size(abi):
         e.submit_seeds([seeds])
         assert_matches_hashed(e.sample_dict(0), d, b, what="hip")
     e.close()
+
+
+def test_baseline_config3_papers_like_full_size(abi, orc):
+    """BASELINE configs[3] shape: papers100M-sized graph (N = 111,059,956, mean degree 14.5, ~1.6 G edges; unsorted
+    rows, cslicer.l0.synth_graph_big), fanout 15/10/5, batch 1024, 8 parts.  Invariants on every stream of a
+    round and bit-exact parity with the oracle on two consecutive minibatches of one worker.  Nothing in the
+    engine scales with N except the CSR itself (7 GB of HBM).  CSLICER_TEST_PAPERS_NODES overrides the size."""
+    import os
+    import time
+    from cslicer import l0
+    n = int(os.environ.get("CSLICER_TEST_PAPERS_NODES", l0.PRESETS["papers-like"][0]))
+    t0 = time.time()
+    indptr, indices = l0.synth_graph_big(n, 14.5, seed=0)
+    t_gen = time.time() - t0
+    perm = np.random.default_rng(1).permutation(n)[:64 * 1024]
+    fan, P, B, S = (15, 10, 5), 8, 1024, 4
+    e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2)
+    e.set_nodes(perm)
+    e.submit_round(0, B, S, slot=0)
+    e.submit_round(S, B, S, slot=1)
+    got0 = [e.sample_dict(s, slot=0) for s in range(S)]
+    for s in range(S):
+        _check_sample_properties(got0[s], indptr, indices, P, fan, perm[s * B:(s + 1) * B])
+    o = orc.Oracle(indptr, indices, n_parts=P, fanouts=fan)
+    assert_same_sample(got0[0], o.sample(perm[:B]), what="papers-like round 0", edge_stream=False)
+    assert_same_sample(e.sample_dict(0, slot=1), o.sample(perm[S * B:(S + 1) * B]), what="papers-like round 1",
+                       edge_stream=False)
+    assert e.device_bytes() < 12 * (1 << 30)
+    e.close()
+    print("papers-like: N=%d E=%d generated in %.0f s" % (n, indices.shape[0], t_gen))
