@@ -148,11 +148,11 @@ def _dense_gat_vectorised(model, trav, feats):
         el, er = (zv * conv.attn_l).sum(-1), (zv * conv.attn_r).sum(-1)
         score = torch.nn.functional.leaky_relu(el[src] + er[dst], conv.slope)            # [E, H]
         n_all = h.shape[0]
-        m = torch.full((n_all, conv.H), -1e30, device=dev).scatter_reduce(
+        m = torch.full((n_all, conv.H), -1e30, device=dev, dtype=h.dtype).scatter_reduce(
             0, dst[:, None].expand(-1, conv.H), score.detach(), "amax", include_self=True)
         p = torch.exp(score - m[dst])
-        ssum = torch.zeros((n_all, conv.H), device=dev).index_add(0, dst, p)
-        num = torch.zeros((n_all, conv.H, conv.D), device=dev).index_add(0, dst, p[:, :, None] * zv[src])
+        ssum = torch.zeros((n_all, conv.H), device=dev, dtype=h.dtype).index_add(0, dst, p)
+        num = torch.zeros((n_all, conv.H, conv.D), device=dev, dtype=h.dtype).index_add(0, dst, p[:, :, None] * zv[src])
         out = (num / ssum.clamp_min(1e-30)[:, :, None]).reshape(n_all, -1) + conv.bias
         new = torch.zeros_like(out).index_copy(0, fr, out[fr])
         if k + 1 < len(model.convs):
@@ -166,8 +166,10 @@ def test_gat_config5_shape_eight_parts(mods):
     """BASELINE configs[4] shape: 3-layer GAT, 8 heads x 32, fanout 10/10/10, batch 1024, EIGHT parts (all in this
     process; products-like degrees on a 400k-node graph so that the dense reference fits), against the unsplit
     definition computed with torch index ops in fp32 on the same sampled graph.  ~10^6 sampled edges and
-    frontiers of ~10^5 nodes: sums of that length differ by summation order, so the tolerances are 1e-4 relative
-    for the outputs (1e-5 holds for the single aggregation kernel, tested above) and 2e-3 for the gradients."""
+    frontiers of ~10^5 nodes.  The reference runs in float64, so what is measured is the fp32 error of the
+    split-parallel path itself: outputs within 1e-4 relative (1e-5 holds for the single aggregation kernel, tested
+    above); gradients, which are sums of ~10^5-10^6 signed fp32 terms, within 1e-3 of the largest entry of the
+    tensor (plus 2e-3 relative)."""
     abi, aggr, sg = mods
     from cslicer import l0
     from oracle import oracle as orc
@@ -191,19 +193,22 @@ def test_gat_config5_shape_eight_parts(mods):
     seeds_t = torch.from_numpy(seeds).cuda()
     sum((out[g] * w[seeds_t[seeds_t % P == g]]).sum() for g in range(P)).backward()
     got_grads = [p.grad.clone() for p in model.parameters()]
-    model.zero_grad()
+    import copy
+    model64 = copy.deepcopy(model).double()
+    model64.zero_grad()
     trav = orc.Oracle(indptr, indices, n_parts=P, fanouts=fan).sample(seeds)
-    fin = feats.clone().requires_grad_()
-    ref = _dense_gat_vectorised(model, trav, fin)
+    fin = feats.double().requires_grad_()
+    ref = _dense_gat_vectorised(model64, trav, fin)
     for g in range(P):
         own = seeds_t[seeds_t % P == g]
-        torch.testing.assert_close(out[g].detach(), ref[own].detach(), rtol=1e-4, atol=1e-5)
-    (ref[seeds_t] * w[seeds_t]).sum().backward()
-    for (name, p_), gg in zip(model.named_parameters(), got_grads):
+        torch.testing.assert_close(out[g].detach(), ref[own].detach().float(), rtol=1e-4, atol=1e-5)
+    (ref[seeds_t] * w[seeds_t].double()).sum().backward()
+    for (name, p_), gg in zip(model64.named_parameters(), got_grads):
         scale = float(p_.grad.abs().max())
-        torch.testing.assert_close(gg, p_.grad, rtol=2e-3, atol=2e-4 * max(scale, 1e-3), msg=lambda m_: "grad " + name + ": " + m_)
+        torch.testing.assert_close(gg, p_.grad.float(), rtol=2e-3, atol=1e-3 * max(scale, 1e-3),
+                                   msg=lambda m_: "grad " + name + ": " + m_)
     for g in range(P):
         ids = slices[L - 1][g].in_nodes.long()
-        scale = float(fin.grad[ids].abs().max())
-        torch.testing.assert_close(x[g].grad, fin.grad[ids], rtol=2e-3, atol=2e-4 * max(scale, 1e-3))
+        want = fin.grad[ids].float()
+        torch.testing.assert_close(x[g].grad, want, rtol=2e-3, atol=1e-3 * max(float(want.abs().max()), 1e-3))
     eng.close()
