@@ -119,15 +119,20 @@ def path_bytes_reference_types(meta_layers, P):
     return B
 
 
-def kernel_bytes_device_layout(name, m, P, layer=0, last=False):
+def kernel_bytes_device_layout(name, m, P, layer=0, last=False, nxt=None):
     """Algorithmic bytes one launch of `name` must move for one minibatch-layer,
     in the engine's own HBM layout (u32 ids, int32 lists; host exports widen to int64).
-    Stated per term in DESIGN.md section 5."""
+    Stated per term in DESIGN.md section 5.  nxt = the next layer's units (k_selfin_degree)."""
     F, E, D, U, C = m["F"], m["E"], m["D"], m["U"], m["C"]
     Q = E + F  # bucket queue entries: one per real candidate
     if name == "k_degree":
-        # layer 0: id, rowinfo gather, ninfo store; later layers read the ninfo k_emit prepared
-        return F * (4 + 8 + 8) if layer == 0 else F * 8
+        # only layer 0 has a k_degree launch of its own: batch ids (int64), row lookup, frontier + ninfo stores
+        return F * (8 + 8 + 4 + 8) if layer == 0 else 0
+    if name == "k_selfin":
+        return F * (4 + 4 + 4 + 4) if last else 0
+    if name == "k_selfin_degree":
+        # this layer's k_selfin and the next layer's k_degree (which reads the ninfo k_emit prepared) in one launch
+        return 0 if last or nxt is None else F * (4 + 4 + 4 + 4) + nxt["F"] * 8
     if name == "k_sample":
         # ids + ninfo, rng words, neighbour gather, candidate + flag store, part mask
         return F * (4 + 8) + D * 4 + E * 4 + C * (4 + 1) + F * 4
@@ -144,8 +149,6 @@ def kernel_bytes_device_layout(name, m, P, layer=0, last=False):
         # (the in-node rank `crank` is stored only for candidates whose node is in the frontier: <= F)
         return (C * 1 + (U + m["in_total"]) * 4 + U * 4 + m["in_total"] * 4 + min(F, m["in_total"]) * 4
                 + F * (4 + 4) + m["node_lists"] * 4 + F * 4 + (0 if last else U * 16))
-    if name == "k_selfin":
-        return F * (4 + 4 + 4 + 4)
     return 0
 
 
@@ -489,10 +492,12 @@ def main():
             stats2 = slot_stats((args.warmup + 2 * args.steps - 1) % NS)
             per_kernel = {}
             for name, (ms, n) in tim.items():
-                if n == 0 or name in ("k_seeds", "k_scan_need", "k_scan_lists", "k_scan_buckets", "k_mt19937_fill"):
-                    per_kernel[name] = {"ms_total": ms, "launches": n}
+                if n == 0 or name in ("k_mt19937_fill", "k_dupseeds", "k_graph"):
+                    if n:
+                        per_kernel[name] = {"ms_total": ms, "launches": n, "avg_us": 1e3 * ms / n}
                     continue
-                nbytes = sum(kernel_bytes_device_layout(name, d, P, l, l == len(stats2) - 1)
+                nbytes = sum(kernel_bytes_device_layout(name, d, P, l, l == len(stats2) - 1,
+                                                        stats2[l + 1] if l + 1 < len(stats2) else None)
                              for l, d in enumerate(stats2)) * args.steps
                 per_kernel[name] = {"ms_total": ms, "launches": n, "avg_us": 1e3 * ms / n,
                                     "alg_bytes_per_launch": nbytes / n,

@@ -246,7 +246,7 @@ int csl_hip_stream(csl_engine* e, int32_t slot, void** out);
 
 /* time the dominant kernels of the last rounds with HIP events on the
  * engine's own stream: enable, run rounds, read back per-kernel totals */
-#define CSL_NUM_KERNELS 14
+#define CSL_NUM_KERNELS 15
 int csl_timing_enable(csl_engine* e, int32_t on);
 int csl_timing_read(csl_engine* e, double* ms_total /*[CSL_NUM_KERNELS]*/,
                     int64_t* launches /*[CSL_NUM_KERNELS]*/);

@@ -16,7 +16,7 @@ MAX_PARTS = 8
 MAX_LAYERS = 4
 ABI_VERSION = 3
 NUM_LISTS = 10
-NUM_KERNELS = 14
+NUM_KERNELS = 15
 (IN_NODES, OUT_NODES, OWNED_OUT_NODES, SELF_IDS_IN, SELF_IDS_OUT, TO_IDS, FROM_IDS,
  INDPTR, INDICES, OWNED_DEGREE) = range(10)
 MODE_STRICT, MODE_GRAPH = 0, 1

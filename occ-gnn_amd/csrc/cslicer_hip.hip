@@ -91,11 +91,11 @@ __host__ __device__ constexpr int NKINDS(int P, bool graph) { return graph ? 3 +
 constexpr int MAXK = 3 + 7 * CSL_MAX_PARTS + CSL_MAX_PARTS * CSL_MAX_PARTS;
 
 enum { KN_SEEDS = 0, KN_DEGREE, KN_SCAN_A, KN_SAMPLE, KN_SCAN_Q, KN_SCATTER, KN_BUCKET, KN_COUNT, KN_SCAN_B,
-       KN_EMIT, KN_SELFIN, KN_MT, KN_EDGES, KN_DUPSEEDS };
+       KN_EMIT, KN_SELFIN, KN_MT, KN_EDGES, KN_DUPSEEDS, KN_SELFIN_DEGREE };
 const char* const kKernelNames[CSL_NUM_KERNELS] = {"k_seeds",   "k_degree", "k_scan_need", "k_sample",
                                                    "k_scan_buckets", "k_scatter", "k_bucket", "k_count",
                                                    "k_scan_lists", "k_emit",  "k_selfin",  "k_mt19937_fill",
-                                                   "k_graph", "k_dupseeds"};
+                                                   "k_graph", "k_dupseeds", "k_selfin_degree"};
 
 // Everything a layer's kernels need; passed by value.
 struct LArgs {
@@ -143,6 +143,8 @@ struct LArgs {
   unsigned long long wmagic;  // ceil(2^40 / W): exact c / W for c < 2^31, W < 512
   uint32_t S;
   uint32_t tpb;               // frontier tiles per k_sample block
+  uint32_t* boff;             // [S][nbmax+1] bucket offsets inside the queue (k_scatter's block 0 -> k_bucket)
+  uint32_t* ticket;           // [S][2] last-block-done tickets (k_degree, k_count)
   uint32_t pmask;             // bit g: the lists of part g are written (csl_config.part_mask; all ones = every part)
   uint32_t last;              // 1 on the final layer (no next frontier to prepare)
   // repeated seed ids (layer 0 only; bipartite.cpp:3-17 on a batch with duplicates): see k_dupseeds
@@ -185,15 +187,34 @@ __device__ __forceinline__ uint32_t div_w(const LArgs& a, uint32_t c) {
 // flags, bucket queue) is touched through ONE L2: scattered narrow stores merge
 // into whole lines there before they reach HBM.  Speed only, never correctness.
 // grid.x = 8 * ceil(S/8) * per_stream.
-__device__ __forceinline__ bool xcd_block(const LArgs& a, uint32_t& x, uint32_t& s) {
+__device__ __forceinline__ bool xcd_block_at(const LArgs& a, uint32_t id, uint32_t grid, uint32_t& x, uint32_t& s) {
   const uint32_t groups = (a.S + 7u) >> 3;
-  const uint32_t per_stream = gridDim.x / (8u * groups);
-  const uint32_t id = blockIdx.x;
+  const uint32_t per_stream = grid / (8u * groups);
   const uint32_t j = id >> 3;
   const uint32_t sl = j / per_stream;
   x = j - sl * per_stream;
   s = sl * 8u + (id & 7u);
   return s < a.S;
+}
+__device__ __forceinline__ bool xcd_block(const LArgs& a, uint32_t& x, uint32_t& s) {
+  return xcd_block_at(a, blockIdx.x, gridDim.x, x, s);
+}
+// Last-block-done: every block of a stream's share of a launch (they all sit behind the same L2, see above)
+// publishes its tile counters, then takes a ticket; the block that draws the last one runs the stream's scan in
+// the same launch instead of a one-block-per-stream kernel of its own.  Release/acquire at agent scope:
+// __threadfence() writes back / invalidates as MI355X_MICROARCH.md's hand-off table prescribes.
+__device__ __forceinline__ bool last_block_of_stream(uint32_t* ticket, uint32_t expected) {
+  __shared__ uint32_t s_last;
+  __threadfence();   // this thread's counter stores are visible device-wide ...
+  __syncthreads();   // ... for every thread of the block, before the ticket is drawn
+  if (threadIdx.x == 0) {
+    const uint32_t t = atomicAdd(ticket, 1u);
+    s_last = t == expected - 1u;
+    if (s_last) *ticket = 0u;  // ready for the next launch (no other block touches it any more)
+  }
+  __syncthreads();
+  if (s_last) __threadfence();  // the other blocks' stores are visible to this one
+  return s_last != 0u;
 }
 __device__ __forceinline__ unsigned long long lt_mask() {
   return (1ull << lane_id()) - 1ull;
@@ -210,86 +231,9 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t v) {
   return x >> (32 - HLOG);
 }
 
-// ---- k_seeds: Slicer::get_sample's copy of the batch into `in` (slicer.cpp:70-74)
-struct BatchDesc {
-  long long offset;  // into the node array
-  int count;
-  int pad;
-};
-
-__global__ __launch_bounds__(TN) void k_seeds(const long long* __restrict__ nodes, const BatchDesc* __restrict__ desc,
-                                              uint32_t* fr0, size_t fr0_stride, uint32_t* fsize,
-                                              csl_sample_meta* meta, uint32_t N, int n_layers, uint32_t* dupflag) {
-  const int s = blockIdx.y;
-  const BatchDesc d = desc[s];
-  const uint32_t i = blockIdx.x * TN + threadIdx.x;
-  if (i == 0) {
-    fsize[s * (CSL_MAX_LAYERS + 1)] = (uint32_t)d.count;
-    for (int l = 1; l <= n_layers; l++) fsize[s * (CSL_MAX_LAYERS + 1) + l] = 0;
-    dupflag[s] = 0;  // set by k_bucket of layer 0, read by k_dupseeds: both later launches on this HIP stream
-    // (meta[s].error was zeroed by a memset on the stream before this launch: a reset in here would race
-    // with the other blocks' atomicOr of CSL_ERR_SEED_RANGE)
-    meta[s].n_seeds = (uint32_t)d.count;
-  }
-  if (i < (uint32_t)d.count) {
-    long long v = nodes[d.offset + i];
-    if (v < 0 || v >= (long long)N) {
-      atomicOr(&meta[s].error, (uint32_t)CSL_ERR_SEED_RANGE);
-      v = 0;
-    }
-    fr0[s * fr0_stride + i] = (uint32_t)v;
-  }
-}
-
-// ---- k_degree: first half of Slicer::neighbour_sample (slicer.cpp:8-9): row
-// offset and degree of every frontier node; counts rng consumers and sampled
-// edges per tile.
-__global__ __launch_bounds__(TN) void k_degree(LArgs a) {
-  // one wave per tile, four consecutive nodes per lane: no LDS, no barrier
-  uint32_t bx, s;
-  if (!xcd_block(a, bx, s)) return;
-  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
-  const uint32_t tile = bx * NW + (threadIdx.x >> 6);
-  if (tile * TN >= F) return;
-  const uint32_t i0 = tile * TN + lane_id() * 4;
-  unsigned long long ri[4] = {0, 0, 0, 0};
-  if (a.layer == 0) {
-    uint32_t v[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = i0 + j < F ? a.fr_in[s * a.fr_in_stride + i0 + j] : UNSET;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (v[j] != UNSET) ri[j] = row_lookup(a, v[j]);
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (v[j] != UNSET) a.ninfo[s * a.fcap + i0 + j] = ri[j];
-  } else {
-    // gathered by the previous layer's k_emit
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (i0 + j < F) ri[j] = a.ninfo[s * a.fcap + i0 + j];
-  }
-  uint32_t need = 0, ne = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (i0 + j < F) {
-      const uint32_t deg = (uint32_t)(ri[j] & DEG_MASK);
-      need += deg >= a.fanout;
-      ne += deg < a.fanout ? deg : a.fanout;
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    need += __shfl_down(need, o);
-    ne += __shfl_down(ne, o);
-  }
-  if (lane_id() == 0) {
-    a.tcnt[((size_t)s * a.nk + K_NEED) * a.tmax + tile] = need;
-    a.tcnt[((size_t)s * a.nk + K_EDGES) * a.tmax + tile] = ne;
-  }
-}
-
-// ---- k_scan: exclusive scan of tile counters kinds [k_lo, k_hi) per stream,
-// then the per-layer bookkeeping that depends on the totals.
+// ---- scan_body: exclusive scan of tile counters kinds [k_lo, k_hi) of one stream, then the per-layer bookkeeping
+// that depends on the totals.  Run by the LAST block of the stream in k_degree (PHASE 0: rng consumers, rng base,
+// bucket geometry) and in k_count (PHASE 1: list offsets, next frontier size): see last_block_of_stream().
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t x, uint32_t& total) {
   uint32_t incl = x;
   for (int o = 1; o < 64; o <<= 1) {
@@ -317,12 +261,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x) {
 // bit g of x (g < 4) -> byte g
 __device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((x & 0xFu) * 0x00204081u) & 0x01010101u; }
 
-constexpr int SCAN_T = 1024;  // k_scan<1>: 16 waves share the 3+6P (or more) kinds of a stream
 constexpr int SCAN_CH = 12;    // tiles a lane keeps in registers (64 x 12 tiles = 196 k frontier nodes)
 
 template <int PHASE>
-__global__ __launch_bounds__(PHASE == 0 ? TN : SCAN_T) void k_scan(LArgs a) {
-  const int s = blockIdx.x;
+__device__ __forceinline__ void scan_body(const LArgs& a, const int s) {
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
   const uint32_t ntiles = (F + TN - 1) / TN;
   const int k_lo = PHASE == 0 ? 0 : 2;
@@ -370,7 +312,10 @@ __global__ __launch_bounds__(PHASE == 0 ? TN : SCAN_T) void k_scan(LArgs a) {
     if (nb < 1) nb = 1;
     if (nb > a.nbmax) nb = a.nbmax;
     if (threadIdx.x == 0) a.nbk[s] = F ? nb : 0;
-    for (uint32_t b = threadIdx.x; b <= a.nbmax; b += blockDim.x) a.bcnt[(size_t)s * (a.nbmax + 1) + b] = 0;
+    for (uint32_t b = threadIdx.x; b <= a.nbmax; b += blockDim.x) {
+      a.bcnt[(size_t)s * (a.nbmax + 1) + b] = 0;
+      if (b < a.nbmax) a.bcur[(size_t)s * a.nbmax + b] = 0;  // k_scatter's cursors count from the bucket's offset
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -441,26 +386,95 @@ __global__ __launch_bounds__(PHASE == 0 ? TN : SCAN_T) void k_scan(LArgs a) {
   }
 }
 
-// ---- k_scan_buckets: bucket sizes -> queue offsets and scatter cursors
-__global__ __launch_bounds__(TN) void k_scan_buckets(LArgs a) {
-  const int s = blockIdx.x;
-  const uint32_t nb = a.nbk[s];
-  if (threadIdx.x >= 64) return;  // one wave
-  uint32_t* cnt = a.bcnt + (size_t)s * (a.nbmax + 1);
-  uint32_t* cur = a.bcur + (size_t)s * a.nbmax;
-  uint32_t run = 0;
-  for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
-    const uint32_t b = b0 + lane_id();
-    const uint32_t x = b < nb ? cnt[b] : 0;
-    uint32_t tot;
-    const uint32_t ex = wave_excl_scan(x, tot);
-    if (b < nb) {
-      cnt[b] = run + ex;
-      cur[b] = run + ex;
+// ---- k_degree: Slicer::get_sample's copy of the batch into `in` (slicer.cpp:70-74; layer 0 only) and the first
+// half of Slicer::neighbour_sample (slicer.cpp:8-9): row offset and degree of every frontier node; counts rng
+// consumers and sampled edges per tile; the stream's last block then runs scan_body<0>.
+struct BatchDesc {
+  long long offset;  // into the node array
+  int count;
+  int pad;
+};
+
+__device__ __forceinline__ void degree_body(const LArgs& a, const uint32_t bx, const uint32_t s, const uint32_t per_stream,
+                                            const long long* __restrict__ nodes, const BatchDesc* __restrict__ desc) {
+  // one wave per tile, four consecutive nodes per lane: no LDS, no barrier before the hand-over
+  uint32_t F;
+  long long noff = 0;
+  if (a.layer == 0) {
+    const BatchDesc d = desc[s];
+    F = (uint32_t)d.count;
+    noff = d.offset;
+    if (bx == 0 && threadIdx.x == 0) {
+      a.fsize[s * (CSL_MAX_LAYERS + 1)] = F;
+      for (uint32_t l = 1; l <= CSL_MAX_LAYERS; l++) a.fsize[s * (CSL_MAX_LAYERS + 1) + l] = 0;
+      a.dupflag[s] = 0;  // set by k_bucket of layer 0, read by k_dupseeds: both later launches on this HIP stream
+      // (meta[s].error was zeroed by a memset on the stream before this launch: a reset in here would race
+      // with the other blocks' atomicOr of CSL_ERR_SEED_RANGE)
+      a.meta[s].n_seeds = F;
     }
-    run += tot;
+  } else {
+    F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
   }
-  if (lane_id() == 0) cnt[nb] = run;
+  const uint32_t tile = bx * NW + (threadIdx.x >> 6);
+  if (tile * TN < F) {
+    const uint32_t i0 = tile * TN + lane_id() * 4;
+    unsigned long long ri[4] = {0, 0, 0, 0};
+    if (a.layer == 0) {
+      uint32_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        v[j] = UNSET;
+        if (i0 + j < F) {
+          long long id = nodes[noff + i0 + j];
+          if (id < 0 || id >= (long long)a.N) {
+            atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_SEED_RANGE);
+            id = 0;
+          }
+          v[j] = (uint32_t)id;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (v[j] != UNSET) ri[j] = row_lookup(a, v[j]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (v[j] != UNSET) {
+          const_cast<uint32_t*>(a.fr_in)[s * a.fr_in_stride + i0 + j] = v[j];
+          a.ninfo[s * a.fcap + i0 + j] = ri[j];
+        }
+      }
+    } else {
+      // gathered by the previous layer's k_emit
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (i0 + j < F) ri[j] = a.ninfo[s * a.fcap + i0 + j];
+    }
+    uint32_t need = 0, ne = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (i0 + j < F) {
+        const uint32_t deg = (uint32_t)(ri[j] & DEG_MASK);
+        need += deg >= a.fanout;
+        ne += deg < a.fanout ? deg : a.fanout;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      need += __shfl_down(need, o);
+      ne += __shfl_down(ne, o);
+    }
+    if (lane_id() == 0) {
+      a.tcnt[((size_t)s * a.nk + K_NEED) * a.tmax + tile] = need;
+      a.tcnt[((size_t)s * a.nk + K_EDGES) * a.tmax + tile] = ne;
+    }
+  }
+  if (last_block_of_stream(a.ticket + 2 * s, per_stream)) scan_body<0>(a, (int)s);
+}
+
+__global__ __launch_bounds__(TN) void k_degree(LArgs a, const long long* __restrict__ nodes,
+                                               const BatchDesc* __restrict__ desc) {
+  uint32_t bx, s;
+  if (!xcd_block(a, bx, s)) return;
+  degree_body(a, bx, s, gridDim.x / (8u * ((a.S + 7u) >> 3)), nodes, desc);
 }
 
 // ---- k_sample: second half of neighbour_sample (slicer.cpp:10-21) + the
@@ -736,16 +750,46 @@ __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
     }
   }
   __syncthreads();
-  uint32_t* cur = a.bcur + (size_t)s * a.nbmax;
+  // Queue offset of every bucket = exclusive scan of the stream's bucket sizes (k_sample's histogram).  Every
+  // block scans them for itself (a few hundred counters out of L2: cheaper than a one-block-per-stream kernel
+  // between k_sample and here); block 0 leaves the offsets in `boff` for k_bucket.
+  const uint32_t* gcnt = a.bcnt + (size_t)s * (a.nbmax + 1);
+  uint32_t gpart = 0;
+  for (uint32_t b = b_lo; b < b_hi; b++) gpart += gcnt[b];
+  const uint32_t lrun = s_part[n];
+  __syncthreads();  // s_part is reused
+  s_part[n] = gpart;
+  __syncthreads();
+  if (n < 64) {
+    uint32_t p4[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      p4[j] = s_part[n * 4 + j];
+      sum += p4[j];
+    }
+    uint32_t tot;
+    uint32_t ex = wave_excl_scan(sum, tot);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      s_part[n * 4 + j] = ex;
+      ex += p4[j];
+    }
+  }
+  __syncthreads();
+  uint32_t* cur = a.bcur + (size_t)s * a.nbmax;  // zeroed by scan_body<0>: reservations count from the bucket's offset
+  uint32_t* boff = a.boff + (size_t)s * (a.nbmax + 1);
   {
-    uint32_t run = s_part[n];
+    uint32_t run = lrun, grun = s_part[n];
     for (uint32_t b = b_lo; b < b_hi; b++) {
       const uint32_t h = s_hist[b];
       s_loff[b] = run;
-      s_gbase[b] = h ? atomicAdd(&cur[b], h) : 0;
+      s_gbase[b] = h ? grun + atomicAdd(&cur[b], h) : 0;
       s_hist[b] = 0;
       run += h;
+      if (bx == 0) boff[b] = grun;
+      grun += gcnt[b];
     }
+    if (bx == 0 && n == TN - 1) boff[nb] = grun;  // the last thread's range ends at nb: the queue's length
   }
   __syncthreads();
   // pass B: place every pair at its sorted LDS position
@@ -832,7 +876,7 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
   __shared__ __attribute__((aligned(16))) uint32_t h_epos[HCAP];
   __shared__ __attribute__((aligned(16))) uint32_t h_self[HCAP];
   const uint32_t n = threadIdx.x;
-  const uint32_t* off = a.bcnt + (size_t)s * (a.nbmax + 1);
+  const uint32_t* off = a.boff + (size_t)s * (a.nbmax + 1);
   const uint2* qs = a.queue + (size_t)s * a.ccap;
   const uint32_t W = a.W;
   uint32_t q0 = off[b], q1 = off[b + 1];
@@ -845,10 +889,8 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
       // h_self = the node's FIRST frontier index.  Only the seed layer can hold a node twice (later frontiers
       // are deduplicated): strict mode then follows bipartite.cpp:3-17 (k_dupseeds); graph mode, whose
       // specification is only defined for distinct seeds, refuses the minibatch.
-      if (atomicMin(&h_self[h], ee.y & ~SELF_BIT) != UNSET) {
-        if (a.graph) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
-        else a.dupflag[s] = 1u;
-      }
+      // (a repeated id shows in the evaluate phase: every occurrence but the first reads a smaller index back)
+      atomicMin(&h_self[h], ee.y & ~SELF_BIT);
       // graph mode: the self entry is a source of its own slice
       if (a.graph) atomicMin(&h_epos[h], (ee.y & ~SELF_BIT) * W);
     } else {
@@ -872,6 +914,10 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     if (ee.y & SELF_BIT) {
       const uint32_t i = ee.y & ~SELF_BIT;
       const uint32_t c = i * W;
+      if (self != i) {  // the id was in the minibatch before
+        if (a.graph) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
+        else a.dupflag[s] = 1u;
+      }
       // k_sample left every flag byte zero: only candidates that are a first occurrence are written
       if (a.graph) {
         const uint32_t fe = epos == c;  // epos already includes the self entry
@@ -922,19 +968,57 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
       }
     }
     __syncthreads();
+    // Insertion of the thread's RC register entries, one probe of EVERY pending entry per step: the compare-and-
+    // swap itself is the probe (it returns the slot's key: UNSET = inserted, the id = already there, else occupied),
+    // so a step is one LDS round trip for all of them instead of a read + CAS chain per entry, one entry after
+    // the other (the kernel is bound by these dependent round trips, not by LDS bandwidth).
     uint32_t hs[RC];
+    bool pend[RC];
 #pragma unroll
-    for (int r = 0; r < RC; r++) hs[r] = e[r].x != UNSET ? insert(e[r]) : UNSET;
+    for (int r = 0; r < RC; r++) {
+      pend[r] = e[r].x != UNSET;
+      hs[r] = pend[r] ? slot_of(e[r].x) : UNSET;
+    }
+    for (uint32_t probes = 0; probes < (uint32_t)HCAP; probes++) {
+      uint32_t kk[RC];
+#pragma unroll
+      for (int r = 0; r < RC; r++) kk[r] = pend[r] ? atomicCAS(&h_key[hs[r]], UNSET, e[r].x) : 0u;
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < RC; r++) {
+        if (!pend[r]) continue;
+        if (kk[r] == UNSET || kk[r] == e[r].x) {
+          pend[r] = false;
+          record(e[r], hs[r]);
+        } else {
+          hs[r] = (hs[r] + 1) & (HCAP - 1);
+          any = true;
+        }
+      }
+      if (!any) break;
+    }
+#pragma unroll
+    for (int r = 0; r < RC; r++) {
+      if (pend[r]) {  // HCAP probes without a free slot
+        atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_BUCKET_FULL);
+        hs[r] = UNSET;
+      }
+    }
     for (uint32_t k = n + RC * BT; k < cnt; k += BT) insert(q[k]);
     __syncthreads();
     {
-      // owner parts first (with a workload table these are loads: all requested before the first store)
-      uint32_t og[RC];
+      // owner parts first (with a workload table these are loads: all requested before the first store), and
+      // every slot value before the first flag store
+      uint32_t og[RC], ep[RC], sf[RC];
 #pragma unroll
-      for (int r = 0; r < RC; r++) og[r] = hs[r] != UNSET ? part_of(e[r].x) : 0u;
+      for (int r = 0; r < RC; r++) {
+        og[r] = hs[r] != UNSET ? part_of(e[r].x) : 0u;
+        ep[r] = hs[r] != UNSET ? h_epos[hs[r]] : UNSET;
+        sf[r] = hs[r] != UNSET ? h_self[hs[r]] : UNSET;
+      }
 #pragma unroll
       for (int r = 0; r < RC; r++)
-        if (hs[r] != UNSET) judge(e[r], h_epos[hs[r]], h_self[hs[r]], og[r]);
+        if (hs[r] != UNSET) judge(e[r], ep[r], sf[r], og[r]);
     }
     for (uint32_t k = n + RC * BT; k < cnt; k += BT) {
       const uint2 ee = q[k];
@@ -953,12 +1037,19 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
 // ---- k_count: per-tile counts of the two candidate-level flags, in
 // traversal order, for the list scans.  One wave per tile, four flag bytes per
 // lane per load.
+__device__ __forceinline__ void count_tile(const LArgs& a, const uint32_t s, const uint32_t tile, const uint32_t F);
+
 __global__ __launch_bounds__(TN) void k_count(LArgs a) {
   uint32_t bx, s;
   if (!xcd_block(a, bx, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
   const uint32_t tile = bx * NW + (threadIdx.x >> 6);
-  if (tile * TN >= F) return;
+  if (tile * TN < F) count_tile(a, s, tile, F);
+  // the stream's last block turns the tile counts into list offsets (was a kernel of its own)
+  if (last_block_of_stream(a.ticket + 2 * s + 1, gridDim.x / (8u * ((a.S + 7u) >> 3)))) scan_body<1>(a, (int)s);
+}
+
+__device__ __forceinline__ void count_tile(const LArgs& a, const uint32_t s, const uint32_t tile, const uint32_t F) {
   const uint32_t W = a.W, P = a.P;
   const uint32_t nodes_here = (F - tile * TN) < (uint32_t)TN ? (F - tile * TN) : (uint32_t)TN;
   const uint32_t nbytes = nodes_here * W;
@@ -1484,10 +1575,8 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
 // ---- k_selfin: self_ids_in (replace(self_ids_in), bipartite.cpp:6): the
 // in-node rank of each frontier node inside its own slice, -1 if it was never
 // sampled as a neighbour.
-__global__ __launch_bounds__(TN) void k_selfin(LArgs a) {
+__device__ __forceinline__ void selfin_body(const LArgs& a, const uint32_t bx, const uint32_t s) {
   // four nodes per thread (stride TN, coalesced), all gathers in flight before the stores
-  uint32_t bx, s;
-  if (!xcd_block(a, bx, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
   const uint32_t i0 = bx * 4 * TN + threadIdx.x;
   if (bx * 4 * TN >= F) return;
@@ -1506,6 +1595,24 @@ __global__ __launch_bounds__(TN) void k_selfin(LArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; j++)
     if (sp[j] != UNSET) ar[sp[j]] = r[j];
+}
+
+__global__ __launch_bounds__(TN) void k_selfin(LArgs a) {
+  uint32_t bx, s;
+  if (!xcd_block(a, bx, s)) return;
+  selfin_body(a, bx, s);
+}
+// k_selfin of layer l and k_degree of layer l+1 both depend on layer l's k_emit only and are small: one launch.
+// Blocks [0, n_degree) are the next layer's k_degree (incl. its last-block scan), the rest this layer's k_selfin.
+__global__ __launch_bounds__(TN) void k_selfin_degree(LArgs a, LArgs nx, uint32_t n_degree) {
+  uint32_t bx, s;
+  if (blockIdx.x < n_degree) {
+    if (!xcd_block_at(nx, blockIdx.x, n_degree, bx, s)) return;
+    degree_body(nx, bx, s, n_degree / (8u * ((nx.S + 7u) >> 3)), nullptr, nullptr);
+  } else {
+    if (!xcd_block_at(a, blockIdx.x - n_degree, gridDim.x - n_degree, bx, s)) return;
+    selfin_body(a, bx, s);
+  }
 }
 
 // ---- k_mt19937_fill: the std::mt19937 stream (slicer.h:33), generated on the
@@ -1697,6 +1804,8 @@ struct csl_engine {
   uint32_t* nbk = nullptr;
   uint32_t* bcnt = nullptr;
   uint32_t* bcur = nullptr;
+  uint32_t* boff = nullptr;    // [nsets][S][nbmax+1]
+  uint32_t* ticket = nullptr;  // [nsets][S][2]
   uint32_t nbmax = 0;
   size_t scatter_lds = 0;
   uint32_t* tcnt = nullptr;
@@ -1961,15 +2070,9 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
   e->desc_inflight[slot] = 1;
   csl_sample_meta* meta = e->meta + (size_t)slot * S;
   HIPCHECK(hipMemsetAsync(meta, 0, sizeof(csl_sample_meta) * (size_t)S, st));  // error bits and stale layer tables
-  {
-    Timed t(e, KN_SEEDS, st);
-    dim3 grid((unsigned)((e->fcap[0] + TN - 1) / TN), S);
-    hipLaunchKernelGGL(k_seeds, grid, dim3(TN), 0, st, nodes_dev, dd,
-                       e->fr[0] + (size_t)slot * S * e->fcap[0], e->fcap[0], fsize, meta, e->N, L,
-                       e->dupflag + (size_t)set * S);
-  }
+  LArgs A[CSL_MAX_LAYERS];
   for (int l = 0; l < L; l++) {
-    LArgs a;
+    LArgs& a = A[l];
     memset(&a, 0, sizeof(a));
     a.rowinfo = e->rowinfo;
     a.off32 = e->off32;
@@ -2018,6 +2121,9 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.S = (uint32_t)S;
     a.last = l == L - 1 ? 1u : 0u;
     a.pmask = e->cfg.part_mask ? e->cfg.part_mask : 0xFFFFFFFFu;
+    a.tpb = (unsigned)((e->fcap[l] + TN - 1) / TN) > 128 ? TPB : 1;  // small layers are latency-bound: one tile per block
+    a.boff = e->boff + (size_t)set * S * (e->nbmax + 1);
+    a.ticket = e->ticket + (size_t)set * S * 2;
     a.graph = e->cfg.mode == CSL_MODE_GRAPH ? 1u : 0u;
     a.ecnt = e->ecnt ? e->ecnt + sF * e->P : nullptr;
     a.srcpos = e->srcpos ? e->srcpos + sC : nullptr;
@@ -2028,36 +2134,37 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.dupout = e->dupout ? e->dupout + (size_t)set * S * e->fcap[0] * e->P : nullptr;
     a.rngend = e->rngend + (size_t)set * S;
     a.candk = e->candk ? e->candk + ((size_t)slot * L + l) * S * e->ccap_max : nullptr;
-    const dim3 blk(TN);
-    const unsigned tiles_in = (unsigned)((e->fcap[l] + TN - 1) / TN);
+  }
+  const dim3 blk(TN);
+  const unsigned xg = 8u * (unsigned)((S + 7) / 8);  // see xcd_block()
+  auto tiles_of = [&](int l) { return (unsigned)((e->fcap[l] + TN - 1) / TN); };
+  auto degree_blocks = [&](int l) { return xg * ((tiles_of(l) + NW - 1) / NW); };
+  // A round is 6 launches per layer (+ k_graph / k_dupseeds): k_degree [batch copy on layer 0, row lookups, its last
+  // block per stream scans the rng consumers] . k_sample . k_scatter [bucket offsets scanned in place] . k_bucket .
+  // k_count [last block per stream: list offsets] . k_emit . k_selfin -- the latter in ONE launch with the next
+  // layer's k_degree (both depend on k_emit only).
+  // The stream's mt19937 position is handed from round to round by k_degree's scan: this round's first one waits
+  // for the previous round's last one.
+  if (e->nsets > 1 && e->chain_valid) HIPCHECK(hipStreamWaitEvent(st, e->chain_event, 0));
+  {
+    Timed t(e, KN_DEGREE, st);
+    hipLaunchKernelGGL(k_degree, dim3(degree_blocks(0)), blk, 0, st, A[0], nodes_dev, (const BatchDesc*)dd);
+  }
+  for (int l = 0; l < L; l++) {
+    const LArgs& a = A[l];
+    const unsigned tiles_in = tiles_of(l);
     const size_t ccap_l = (size_t)tiles_in * TN * a.W;
-    const unsigned xg = 8u * (unsigned)((S + 7) / 8);  // see xcd_block()
     const dim3 grid_in(xg * tiles_in);
-    // small layers are latency-bound: one tile per block; large ones amortise the
-    // bucket-histogram flush over TPB tiles
-    a.tpb = tiles_in > 128 ? TPB : 1;
     const dim3 grid_sample(xg * ((tiles_in + a.tpb - 1) / a.tpb));
     const dim3 grid_scatter(xg * (unsigned)((ccap_l + SCT - 1) / SCT));
     unsigned nb_l = (unsigned)((ccap_l + QMEAN - 1) / QMEAN);
     if (nb_l > e->nbmax) nb_l = e->nbmax;
     const dim3 grid_bucket(xg * ((nb_l + BPB - 1) / BPB));
     const size_t lds_hist = (size_t)e->nbmax * sizeof(uint32_t);
-    {
-      Timed t(e, KN_DEGREE, st);
-      hipLaunchKernelGGL(k_degree, dim3(xg * ((tiles_in + NW - 1) / NW)), blk, 0, st, a);
-    }
-    // the stream's mt19937 position is handed from round to round: this round's first update
-    // waits for the previous round's last one (its k_seeds / first k_degree did not have to)
-    if (l == 0 && e->nsets > 1 && e->chain_valid) HIPCHECK(hipStreamWaitEvent(st, e->chain_event, 0));
-    {
-      Timed t(e, KN_SCAN_A, st);
-      hipLaunchKernelGGL(k_scan<0>, dim3(S), blk, 0, st, a);
-    }
-    if (l == L - 1) {
-      if (e->nsets > 1) {
-        HIPCHECK(hipEventRecord(e->chain_event, st));
-        e->chain_valid = true;
-      }
+    if (l == L - 1 && e->nsets > 1) {
+      // (recorded after the launch that holds the round's last position update: the last layer's k_degree)
+      HIPCHECK(hipEventRecord(e->chain_event, st));
+      e->chain_valid = true;
     }
     {
       Timed t(e, KN_SAMPLE, st);
@@ -2080,10 +2187,6 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
       e->snap_pending[k] = true;
     }
     {
-      Timed t(e, KN_SCAN_Q, st);
-      hipLaunchKernelGGL(k_scan_buckets, dim3(S), blk, 0, st, a);
-    }
-    {
       Timed t(e, KN_SCATTER, st);
       hipLaunchKernelGGL(k_scatter, grid_scatter, blk, e->scatter_lds, st, a);
     }
@@ -2097,10 +2200,6 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
       hipLaunchKernelGGL(k_count, dim3(xg * ((tiles_in + NW - 1) / NW)), blk, 0, st, a);
     }
     {
-      Timed t(e, KN_SCAN_B, st);
-      hipLaunchKernelGGL(k_scan<1>, dim3(S), dim3(SCAN_T), 0, st, a);
-    }
-    {
       Timed t(e, KN_EMIT, st);
       hipLaunchKernelGGL(k_emit, grid_in, blk, 0, st, a);
     }
@@ -2112,9 +2211,14 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
       Timed t(e, KN_DUPSEEDS, st);
       hipLaunchKernelGGL(k_dupseeds, dim3(S), dim3(DS_T), 0, st, a);
     }
-    {
+    const unsigned n_selfin = xg * ((tiles_in + 3) / 4);
+    if (l + 1 < L) {
+      Timed t(e, KN_SELFIN_DEGREE, st);
+      const unsigned n_degree = degree_blocks(l + 1);
+      hipLaunchKernelGGL(k_selfin_degree, dim3(n_degree + n_selfin), blk, 0, st, a, A[l + 1], n_degree);
+    } else {
       Timed t(e, KN_SELFIN, st);
-      hipLaunchKernelGGL(k_selfin, dim3(xg * ((tiles_in + 3) / 4)), blk, 0, st, a);
+      hipLaunchKernelGGL(k_selfin, dim3(n_selfin), blk, 0, st, a);
     }
   }
   HIPCHECK(hipGetLastError());
@@ -2150,7 +2254,7 @@ void csl_destroy(csl_engine* e) {
                   e->rngbase, e->ninfo,   e->hasedge, e->selfpos, e->firstpos, e->cand, e->cflag, e->crank,
                   e->queue,   e->nbk,     e->bcnt,    e->bcur,    e->tcnt,     e->fsize, e->meta, e->desc_dev,
                   e->ecnt,    e->srcpos,  e->acc,     e->dupflag, e->seedrep, e->dupfirst, e->dupout, e->rngend,
-                  e->candk};
+                  e->candk,   e->boff,    e->ticket};
   for (void* p : ptrs)
     if (p) hipFree(p);
   for (int l = 0; l <= CSL_MAX_LAYERS; l++)
@@ -2282,6 +2386,9 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   DMALLOC(e->nbk, e->nsets * (size_t)S);
   DMALLOC(e->bcnt, e->nsets * (size_t)S * (e->nbmax + 1));
   DMALLOC(e->bcur, e->nsets * (size_t)S * e->nbmax);
+  DMALLOC(e->boff, e->nsets * (size_t)S * (e->nbmax + 1));
+  DMALLOC(e->ticket, e->nsets * (size_t)S * 2);
+  HIPCHECK(hipMemsetAsync(e->ticket, 0, sizeof(uint32_t) * e->nsets * S * 2, e->stream));
   DMALLOC(e->tcnt, e->nsets * (size_t)S * e->nk * e->tmax);
   DMALLOC(e->fsize, e->nsets * (size_t)S * (CSL_MAX_LAYERS + 1));
   DMALLOC(e->rngpos, (size_t)S);
