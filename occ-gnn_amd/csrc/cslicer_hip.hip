@@ -199,21 +199,30 @@ __device__ __forceinline__ bool xcd_block_at(const LArgs& a, uint32_t id, uint32
 __device__ __forceinline__ bool xcd_block(const LArgs& a, uint32_t& x, uint32_t& s) {
   return xcd_block_at(a, blockIdx.x, gridDim.x, x, s);
 }
-// Last-block-done: every block of a stream's share of a launch (they all sit behind the same L2, see above)
-// publishes its tile counters, then takes a ticket; the block that draws the last one runs the stream's scan in
-// the same launch instead of a one-block-per-stream kernel of its own.  Release/acquire at agent scope:
-// __threadfence() writes back / invalidates as MI355X_MICROARCH.md's hand-off table prescribes.
+// Last-block-done: every block of a stream's share of a launch publishes its tile counters, then takes a ticket;
+// the block that draws the last one runs the stream's scan in the same launch instead of a one-block-per-stream
+// kernel of its own.  Hand-off form of MI355X_MICROARCH.md (inter-workgroup visibility, first table row): the
+// counters are stored AND loaded `sc1` (write-through / L1-bypassing: __hip_atomic_store/load, relaxed, agent
+// scope), every storing wave drains its stores (`s_waitcnt vmcnt(0)`) before the workgroup barrier behind which ONE
+// lane adds to the stream's ticket counter (agent-scope atomic); the workgroup whose add came last, told by the
+// value the add returned, loads -- its other waves after a workgroup barrier the adding wave joins.  No agent fence:
+// a `__threadfence()` here writes back the whole XCD L2 from every thread (k_count: 30 us -> 670 us).
+__device__ __forceinline__ void st_sc1(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_sc1(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ bool last_block_of_stream(uint32_t* ticket, uint32_t expected) {
   __shared__ uint32_t s_last;
-  __threadfence();   // this thread's counter stores are visible device-wide ...
-  __syncthreads();   // ... for every thread of the block, before the ticket is drawn
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's counter stores have left the CU
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t t = atomicAdd(ticket, 1u);
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t == expected - 1u;
-    if (s_last) *ticket = 0u;  // ready for the next launch (no other block touches it any more)
+    if (t == expected - 1u) st_sc1(ticket, 0u);  // ready for the next launch (no other block touches it any more)
   }
   __syncthreads();
-  if (s_last) __threadfence();  // the other blocks' stores are visible to this one
   return s_last != 0u;
 }
 __device__ __forceinline__ unsigned long long lt_mask() {
@@ -265,7 +274,8 @@ constexpr int SCAN_CH = 12;    // tiles a lane keeps in registers (64 x 12 tiles
 
 template <int PHASE>
 __device__ __forceinline__ void scan_body(const LArgs& a, const int s) {
-  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  // (every word another block of this launch wrote is read `sc1`: see last_block_of_stream)
+  const uint32_t F = ld_sc1(&a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer]);
   const uint32_t ntiles = (F + TN - 1) / TN;
   const int k_lo = PHASE == 0 ? 0 : 2;
   const int k_hi = PHASE == 0 ? 2 : (int)a.nk;
@@ -280,7 +290,7 @@ __device__ __forceinline__ void scan_body(const LArgs& a, const int s) {
       uint32_t x[SCAN_CH], sum = 0;
 #pragma unroll
       for (int j = 0; j < SCAN_CH; j++) {
-        x[j] = ((uint32_t)j < chunk && t0 + j < ntiles) ? p[t0 + j] : 0u;
+        x[j] = ((uint32_t)j < chunk && t0 + j < ntiles) ? ld_sc1(&p[t0 + j]) : 0u;
         sum += x[j];
       }
       uint32_t tot;
@@ -295,7 +305,7 @@ __device__ __forceinline__ void scan_body(const LArgs& a, const int s) {
       uint32_t run = 0;
       for (uint32_t t0 = 0; t0 < ntiles; t0 += 64) {
         const uint32_t t = t0 + lane_id();
-        const uint32_t x = t < ntiles ? p[t] : 0;
+        const uint32_t x = t < ntiles ? ld_sc1(&p[t]) : 0;
         uint32_t tot;
         const uint32_t ex = wave_excl_scan(x, tot);
         if (t < ntiles) p[t] = run + ex;
@@ -405,7 +415,7 @@ __device__ __forceinline__ void degree_body(const LArgs& a, const uint32_t bx, c
     F = (uint32_t)d.count;
     noff = d.offset;
     if (bx == 0 && threadIdx.x == 0) {
-      a.fsize[s * (CSL_MAX_LAYERS + 1)] = F;
+      st_sc1(&a.fsize[s * (CSL_MAX_LAYERS + 1)], F);  // read by the stream's last block in this launch
       for (uint32_t l = 1; l <= CSL_MAX_LAYERS; l++) a.fsize[s * (CSL_MAX_LAYERS + 1) + l] = 0;
       a.dupflag[s] = 0;  // set by k_bucket of layer 0, read by k_dupseeds: both later launches on this HIP stream
       // (meta[s].error was zeroed by a memset on the stream before this launch: a reset in here would race
@@ -463,8 +473,8 @@ __device__ __forceinline__ void degree_body(const LArgs& a, const uint32_t bx, c
       ne += __shfl_down(ne, o);
     }
     if (lane_id() == 0) {
-      a.tcnt[((size_t)s * a.nk + K_NEED) * a.tmax + tile] = need;
-      a.tcnt[((size_t)s * a.nk + K_EDGES) * a.tmax + tile] = ne;
+      st_sc1(&a.tcnt[((size_t)s * a.nk + K_NEED) * a.tmax + tile], need);
+      st_sc1(&a.tcnt[((size_t)s * a.nk + K_EDGES) * a.tmax + tile], ne);
     }
   }
   if (last_block_of_stream(a.ticket + 2 * s, per_stream)) scan_body<0>(a, (int)s);
@@ -1101,7 +1111,7 @@ __device__ __forceinline__ void count_tile(const LArgs& a, const uint32_t s, con
   if (lane_id() == 0) {
 #pragma unroll
     for (int k = 0; k < 1 + CSL_MAX_PARTS; k++)
-      if (k < 1 + (int)P) a.tcnt[((size_t)s * a.nk + (K_NEWF + k)) * a.tmax + tile] = cnt[k];
+      if (k < 1 + (int)P) st_sc1(&a.tcnt[((size_t)s * a.nk + (K_NEWF + k)) * a.tmax + tile], cnt[k]);
   }
 }
 
