@@ -978,10 +978,11 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
       }
     }
     __syncthreads();
-    // Insertion of the thread's RC register entries, one probe of EVERY pending entry per step: the compare-and-
-    // swap itself is the probe (it returns the slot's key: UNSET = inserted, the id = already there, else occupied),
-    // so a step is one LDS round trip for all of them instead of a read + CAS chain per entry, one entry after
-    // the other (the kernel is bound by these dependent round trips, not by LDS bandwidth).
+    // Insertion of the thread's RC register entries, one probe of EVERY pending entry per step (read the slot; where
+    // it is free, compare-and-swap): two LDS round trips for all of them instead of a read + CAS chain per entry, one
+    // entry after the other -- the kernel is bound by these dependent round trips, not by LDS bandwidth.  (Probing
+    // with the CAS alone, one round trip, was slower: 196 vs 160 us -- an id's many occurrences then all hit its
+    // slot with atomics, which serialise, where plain reads of one address broadcast.)
     uint32_t hs[RC];
     bool pend[RC];
 #pragma unroll
@@ -992,7 +993,10 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     for (uint32_t probes = 0; probes < (uint32_t)HCAP; probes++) {
       uint32_t kk[RC];
 #pragma unroll
-      for (int r = 0; r < RC; r++) kk[r] = pend[r] ? atomicCAS(&h_key[hs[r]], UNSET, e[r].x) : 0u;
+      for (int r = 0; r < RC; r++) kk[r] = pend[r] ? h_key[hs[r]] : 0u;
+#pragma unroll
+      for (int r = 0; r < RC; r++)
+        if (pend[r] && kk[r] == UNSET) kk[r] = atomicCAS(&h_key[hs[r]], UNSET, e[r].x);
       bool any = false;
 #pragma unroll
       for (int r = 0; r < RC; r++) {
@@ -1049,11 +1053,12 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
 // lane per load.
 __device__ __forceinline__ void count_tile(const LArgs& a, const uint32_t s, const uint32_t tile, const uint32_t F);
 
-__global__ __launch_bounds__(TN) void k_count(LArgs a) {
+constexpr int CNT_T = 1024;  // k_count: 16 waves = 16 tiles per block; the stream's last block scans 3+6P kinds with them
+__global__ __launch_bounds__(CNT_T) void k_count(LArgs a) {
   uint32_t bx, s;
   if (!xcd_block(a, bx, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
-  const uint32_t tile = bx * NW + (threadIdx.x >> 6);
+  const uint32_t tile = bx * (CNT_T / 64) + (threadIdx.x >> 6);
   if (tile * TN < F) count_tile(a, s, tile, F);
   // the stream's last block turns the tile counts into list offsets (was a kernel of its own)
   if (last_block_of_stream(a.ticket + 2 * s + 1, gridDim.x / (8u * ((a.S + 7u) >> 3)))) scan_body<1>(a, (int)s);
@@ -2207,7 +2212,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     }
     {
       Timed t(e, KN_COUNT, st);
-      hipLaunchKernelGGL(k_count, dim3(xg * ((tiles_in + NW - 1) / NW)), blk, 0, st, a);
+      hipLaunchKernelGGL(k_count, dim3(xg * ((tiles_in + CNT_T / 64 - 1) / (CNT_T / 64))), dim3(CNT_T), 0, st, a);
     }
     {
       Timed t(e, KN_EMIT, st);
