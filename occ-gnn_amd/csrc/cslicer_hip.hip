@@ -477,7 +477,12 @@ __device__ __forceinline__ void degree_body(const LArgs& a, const uint32_t bx, c
       st_sc1(&a.tcnt[((size_t)s * a.nk + K_EDGES) * a.tmax + tile], ne);
     }
   }
-  if (last_block_of_stream(a.ticket + 2 * s, per_stream)) scan_body<0>(a, (int)s);
+  // blocks without a tile leave at once; block 0 always stays (an empty minibatch still needs its bookkeeping)
+  uint32_t nb_act = ((F + TN - 1) / TN + NW - 1) / NW;
+  if (nb_act < 1) nb_act = 1;
+  if (nb_act > per_stream) nb_act = per_stream;
+  if (bx >= nb_act) return;
+  if (last_block_of_stream(a.ticket + 2 * s, nb_act)) scan_body<0>(a, (int)s);
 }
 
 __global__ __launch_bounds__(TN) void k_degree(LArgs a, const long long* __restrict__ nodes,
@@ -984,6 +989,10 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     // with the CAS alone, one round trip, was slower: 196 vs 160 us -- an id's many occurrences then all hit its
     // slot with atomics, which serialise, where plain reads of one address broadcast.)
     uint32_t hs[RC];
+#ifdef CSL_SEQ_INSERT
+#pragma unroll
+    for (int r = 0; r < RC; r++) hs[r] = e[r].x != UNSET ? insert(e[r]) : UNSET;
+#else
     bool pend[RC];
 #pragma unroll
     for (int r = 0; r < RC; r++) {
@@ -1018,6 +1027,7 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
         hs[r] = UNSET;
       }
     }
+#endif
     for (uint32_t k = n + RC * BT; k < cnt; k += BT) insert(q[k]);
     __syncthreads();
     {
@@ -1061,7 +1071,12 @@ __global__ __launch_bounds__(CNT_T) void k_count(LArgs a) {
   const uint32_t tile = bx * (CNT_T / 64) + (threadIdx.x >> 6);
   if (tile * TN < F) count_tile(a, s, tile, F);
   // the stream's last block turns the tile counts into list offsets (was a kernel of its own)
-  if (last_block_of_stream(a.ticket + 2 * s + 1, gridDim.x / (8u * ((a.S + 7u) >> 3)))) scan_body<1>(a, (int)s);
+  const uint32_t per_stream = gridDim.x / (8u * ((a.S + 7u) >> 3));
+  uint32_t nb_act = ((F + TN - 1) / TN + CNT_T / 64 - 1) / (CNT_T / 64);
+  if (nb_act < 1) nb_act = 1;
+  if (nb_act > per_stream) nb_act = per_stream;
+  if (bx >= nb_act) return;  // blocks without a tile leave at once; block 0 always stays
+  if (last_block_of_stream(a.ticket + 2 * s + 1, nb_act)) scan_body<1>(a, (int)s);
 }
 
 __device__ __forceinline__ void count_tile(const LArgs& a, const uint32_t s, const uint32_t tile, const uint32_t F) {
