@@ -145,6 +145,7 @@ struct LArgs {
   uint32_t tpb;               // frontier tiles per k_sample block
   uint32_t* boff;             // [S][nbmax+1] bucket offsets inside the queue (k_scatter's block 0 -> k_bucket)
   uint32_t* ticket;           // [S][2] last-block-done tickets (k_degree, k_count)
+  uint32_t pmagic;            // floor(2^32 / P) (P >= 2), see mod_parts()
   uint32_t pmask;             // bit g: the lists of part g are written (csl_config.part_mask; all ones = every part)
   uint32_t last;              // 1 on the final layer (no next frontier to prepare)
   // repeated seed ids (layer 0 only; bipartite.cpp:3-17 on a batch with duplicates): see k_dupseeds
@@ -164,8 +165,16 @@ struct LArgs {
 
 constexpr uint32_t SELF_BIT = 0x80000000u;
 
+// v % P for the runtime constant P (pyfrontend.cpp:57 workload_map[j] = j % 4) without the ~25-instruction
+// software division: q = floor(v * floor(2^32 / P) / 2^32) is the quotient or one short of it.
+__device__ __forceinline__ uint32_t mod_parts(const LArgs& a, uint32_t v) {
+  uint32_t r = v - __umulhi(v, a.pmagic) * a.P;
+  if (r >= a.P) r -= a.P;
+  if (r >= a.P) r -= a.P;
+  return r;
+}
 __device__ __forceinline__ uint32_t owner(const LArgs& a, uint32_t v) {
-  return a.wl ? (uint32_t)a.wl[v] : (v % a.P);
+  return a.wl ? (uint32_t)a.wl[v] : mod_parts(a, v);
 }
 // row offset and degree of node v, in ninfo's packed form (the gather of slicer.cpp:8-9).  With 32-bit
 // offsets the lookup table is 4 B per node instead of 8: the random gathers of a layer touch the same
@@ -328,9 +337,9 @@ __device__ __forceinline__ void scan_body(const LArgs& a, const int s) {
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    csl_layer_meta& m = a.meta[s].layer[a.layer];
-    if (PHASE == 0) {
+  csl_layer_meta& m = a.meta[s].layer[a.layer];
+  if (PHASE == 0) {
+    if (threadIdx.x == 0) {
       const unsigned long long base = a.rngpos[s];
       const unsigned long long draws = (unsigned long long)s_tot[K_NEED] * a.fanout;
       a.rngbase[s] = base;
@@ -343,8 +352,38 @@ __device__ __forceinline__ void scan_body(const LArgs& a, const int s) {
       m.frontier = F;
       m.draws = (uint32_t)draws;
       m.sampled_edges = s_tot[K_EDGES];
-    } else {
-      const int P = (int)a.P;
+    }
+  } else {
+    // the layer's offset tables: one thread per list kind (and per part for the boundary pairs), not one for all
+    const int P = (int)a.P;
+    const uint32_t t = threadIdx.x;
+    auto pair_sum = [&](int g, bool from) -> uint32_t {
+      uint32_t x = 0;
+      for (int p = 0; p < P; p++) x += from ? s_tot[K_PAIR(P, g, p)] : s_tot[K_PAIR(P, p, g)];
+      return x;
+    };
+    auto tot_of = [&](int kind, int g) -> uint32_t {
+      switch (kind) {
+        case CSL_IN_NODES: return s_tot[K_IN(P, g)];
+        case CSL_OUT_NODES: return s_tot[K_OUT(P, g)];
+        case CSL_OWNED_OUT_NODES: return s_tot[K_OWNED(P, g)];
+        case CSL_SELF_IDS_IN:
+        case CSL_SELF_IDS_OUT: return s_tot[K_SELF(P, g)];
+        case CSL_TO_IDS: return a.graph ? pair_sum(g, false) : s_tot[K_TO(P, g)];
+        case CSL_FROM_IDS: return a.graph ? pair_sum(g, true) : s_tot[K_FROM(P, g)];
+        case CSL_INDPTR: return a.graph ? (F ? s_tot[K_OUT(P, g)] + 1 : 0u) : 0u;
+        case CSL_INDICES: return a.graph ? s_tot[K_ECNT(P, g)] : 0u;
+        default: return a.graph ? s_tot[K_OWNED(P, g)] : 0u;  // CSL_OWNED_DEGREE
+      }
+    };
+    if (t < (uint32_t)CSL_NUM_LISTS) {
+      uint32_t run = 0;
+      for (int g = 0; g < P; g++) {
+        m.off[t][g] = run;
+        run += tot_of((int)t, g);
+      }
+      for (int g = P; g <= CSL_MAX_PARTS; g++) m.off[t][g] = run;
+    } else if (t == 16) {
       uint32_t nf = s_tot[K_NEWF];
       if (nf > a.fr_out_cap) {
         atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_FRONTIER_CAP);
@@ -352,46 +391,22 @@ __device__ __forceinline__ void scan_body(const LArgs& a, const int s) {
       }
       m.next_frontier = nf;
       a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer + 1] = nf;
-      uint32_t tot[CSL_NUM_LISTS][CSL_MAX_PARTS];
-      for (int g = 0; g < P; g++) {
-        tot[CSL_IN_NODES][g] = s_tot[K_IN(P, g)];
-        tot[CSL_OUT_NODES][g] = s_tot[K_OUT(P, g)];
-        tot[CSL_OWNED_OUT_NODES][g] = s_tot[K_OWNED(P, g)];
-        tot[CSL_SELF_IDS_IN][g] = s_tot[K_SELF(P, g)];
-        tot[CSL_SELF_IDS_OUT][g] = s_tot[K_SELF(P, g)];
-        if (!a.graph) {
-          tot[CSL_TO_IDS][g] = s_tot[K_TO(P, g)];
-          tot[CSL_FROM_IDS][g] = s_tot[K_FROM(P, g)];
-          tot[CSL_INDPTR][g] = tot[CSL_INDICES][g] = tot[CSL_OWNED_DEGREE][g] = 0;
-        } else {
-          uint32_t fr = 0, to = 0;
-          for (int p = 0; p < P; p++) {
-            m.pair_off[0][g][p] = fr;  // (g -> p) inside slice g's from_ids
-            m.pair_off[1][g][p] = to;  // (p -> g) inside slice g's to_ids
-            fr += s_tot[K_PAIR(P, g, p)];
-            to += s_tot[K_PAIR(P, p, g)];
-          }
-          for (int p = P; p <= CSL_MAX_PARTS; p++) {
-            m.pair_off[0][g][p] = fr;
-            m.pair_off[1][g][p] = to;
-          }
-          tot[CSL_FROM_IDS][g] = fr;
-          tot[CSL_TO_IDS][g] = to;
-          tot[CSL_INDPTR][g] = F ? tot[CSL_OUT_NODES][g] + 1 : 0;
-          tot[CSL_INDICES][g] = s_tot[K_ECNT(P, g)];
-          tot[CSL_OWNED_DEGREE][g] = tot[CSL_OWNED_OUT_NODES][g];
-        }
-      }
-      for (int kind = 0; kind < CSL_NUM_LISTS; kind++) {
-        uint32_t run = 0;
-        for (int g = 0; g < P; g++) {
-          m.off[kind][g] = run;
-          run += tot[kind][g];
-        }
-        for (int g = P; g <= CSL_MAX_PARTS; g++) m.off[kind][g] = run;
-      }
+    } else if (t == 17) {
       for (int g = 0; g < CSL_MAX_PARTS; g++)
-        m.indptr_len[g] = g < P ? (a.graph ? tot[CSL_INDPTR][g] : tot[CSL_OUT_NODES][g]) : 0u;
+        m.indptr_len[g] = g < P ? tot_of(a.graph ? CSL_INDPTR : CSL_OUT_NODES, g) : 0u;
+    } else if (a.graph && t >= 32 && t < 32u + (uint32_t)P) {
+      const int g = (int)t - 32;
+      uint32_t fr = 0, to = 0;
+      for (int p = 0; p < P; p++) {
+        m.pair_off[0][g][p] = fr;  // (g -> p) inside slice g's from_ids
+        m.pair_off[1][g][p] = to;  // (p -> g) inside slice g's to_ids
+        fr += s_tot[K_PAIR(P, g, p)];
+        to += s_tot[K_PAIR(P, p, g)];
+      }
+      for (int p = P; p <= CSL_MAX_PARTS; p++) {
+        m.pair_off[0][g][p] = fr;
+        m.pair_off[1][g][p] = to;
+      }
     }
   }
 }
@@ -922,7 +937,7 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     return h;
   };
   uint8_t* cflag = a.cflag + (size_t)s * a.ccap;
-  auto part_of = [&](const uint32_t v) -> uint32_t { return HAS_WL ? (uint32_t)a.wl[v] : (v % a.P); };
+  auto part_of = [&](const uint32_t v) -> uint32_t { return HAS_WL ? (uint32_t)a.wl[v] : mod_parts(a, v); };
   // what an entry learns from its slot (epos = first edge position of the node, self = its frontier index);
   // g = owner part of the node
   auto judge = [&](const uint2 ee, const uint32_t epos, const uint32_t self, const uint32_t g) {
@@ -983,51 +998,12 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
       }
     }
     __syncthreads();
-    // Insertion of the thread's RC register entries, one probe of EVERY pending entry per step (read the slot; where
-    // it is free, compare-and-swap): two LDS round trips for all of them instead of a read + CAS chain per entry, one
-    // entry after the other -- the kernel is bound by these dependent round trips, not by LDS bandwidth.  (Probing
-    // with the CAS alone, one round trip, was slower: 196 vs 160 us -- an id's many occurrences then all hit its
-    // slot with atomics, which serialise, where plain reads of one address broadcast.)
+    // (one entry after the other: probing all four register entries together, reads then the CAS of the empty
+    // slots, was measured slower twice -- 204 us in round 1, 215 us in round 2 against 158 -- and probing with the
+    // CAS alone 196 us: an id's many occurrences then hit its slot with atomics, which serialise)
     uint32_t hs[RC];
-#ifdef CSL_SEQ_INSERT
 #pragma unroll
     for (int r = 0; r < RC; r++) hs[r] = e[r].x != UNSET ? insert(e[r]) : UNSET;
-#else
-    bool pend[RC];
-#pragma unroll
-    for (int r = 0; r < RC; r++) {
-      pend[r] = e[r].x != UNSET;
-      hs[r] = pend[r] ? slot_of(e[r].x) : UNSET;
-    }
-    for (uint32_t probes = 0; probes < (uint32_t)HCAP; probes++) {
-      uint32_t kk[RC];
-#pragma unroll
-      for (int r = 0; r < RC; r++) kk[r] = pend[r] ? h_key[hs[r]] : 0u;
-#pragma unroll
-      for (int r = 0; r < RC; r++)
-        if (pend[r] && kk[r] == UNSET) kk[r] = atomicCAS(&h_key[hs[r]], UNSET, e[r].x);
-      bool any = false;
-#pragma unroll
-      for (int r = 0; r < RC; r++) {
-        if (!pend[r]) continue;
-        if (kk[r] == UNSET || kk[r] == e[r].x) {
-          pend[r] = false;
-          record(e[r], hs[r]);
-        } else {
-          hs[r] = (hs[r] + 1) & (HCAP - 1);
-          any = true;
-        }
-      }
-      if (!any) break;
-    }
-#pragma unroll
-    for (int r = 0; r < RC; r++) {
-      if (pend[r]) {  // HCAP probes without a free slot
-        atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_BUCKET_FULL);
-        hs[r] = UNSET;
-      }
-    }
-#endif
     for (uint32_t k = n + RC * BT; k < cnt; k += BT) insert(q[k]);
     __syncthreads();
     {
@@ -2151,6 +2127,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.S = (uint32_t)S;
     a.last = l == L - 1 ? 1u : 0u;
     a.pmask = e->cfg.part_mask ? e->cfg.part_mask : 0xFFFFFFFFu;
+    a.pmagic = e->P > 1 ? (uint32_t)((1ull << 32) / (unsigned)e->P) : 0xFFFFFFFFu;  // (P == 1: q = v - 1, r = 1 -> 0)
     a.tpb = (unsigned)((e->fcap[l] + TN - 1) / TN) > 128 ? TPB : 1;  // small layers are latency-bound: one tile per block
     a.boff = e->boff + (size_t)set * S * (e->nbmax + 1);
     a.ticket = e->ticket + (size_t)set * S * 2;
