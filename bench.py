@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--e2e-feat", type=int, default=100)
     ap.add_argument("--e2e-classes", type=int, default=47)
     ap.add_argument("--e2e-streams", type=int, default=8, help="minibatches the trainer's engine slices per round")
+    ap.add_argument("--same-batch", action="store_true",
+                    help="experiment (profiles/pmc_same_batch.sh): every stream slices the SAME minibatch, so all S "
+                         "streams visit the same rows at the same time -- the ceiling of what grouping the streams' "
+                         "frontier nodes by row could save in k_sample's fetches; results are not a throughput figure")
     ap.add_argument("--selftest-dist", choices=("ok", "e2e-fail", "e2e-hang"), default=None,
                     help="no GPU work at all: rendezvous (gloo), reductions, the guarded e2e leg with a stand-in body, "
                          "the single JSON line and the shutdown path -- what tests/test_bench_launch.py runs on CPU")
@@ -374,6 +378,10 @@ def main():
     def run_round(step):
         # weak scaling: rank r takes its own rounds (cslicer/shard.py); wraps around the epoch
         first, nb = shard.batches_of_round(shard.round_of(step, rank, world, n_rounds), S)
+        if args.same_batch:
+            k = step % max(1, n_batches)
+            eng.submit_seeds([perm[k * B:(k + 1) * B]] * S, slot=step % NS)
+            return
         eng.submit_round(first, B, nb, slot=step % NS)
 
     def timed(nsteps, first_step):
