@@ -38,6 +38,7 @@ for p in (ROOT, os.path.join(ROOT, "occ-gnn_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_MFMA_PEAK_TFS = 157.3  # MI355X dense fp32 matrix peak (the trainer's GEMMs are fp32, like the reference's)
 
 
 def parse():
@@ -75,6 +76,7 @@ def parse():
     ap.add_argument("--e2e-feat", type=int, default=100)
     ap.add_argument("--e2e-classes", type=int, default=47)
     ap.add_argument("--e2e-streams", type=int, default=8, help="minibatches the trainer's engine slices per round")
+    ap.add_argument("--no-compat", action="store_true", help="skip the reference-surface (host lists) leg")
     ap.add_argument("--same-batch", action="store_true",
                     help="experiment (profiles/pmc_same_batch.sh): every stream slices the SAME minibatch, so all S "
                          "streams visit the same rows at the same time -- the ceiling of what grouping the streams' "
@@ -154,6 +156,41 @@ def kernel_bytes_device_layout(name, m, P, layer=0, last=False, nxt=None):
         return (C * 1 + (U + m["in_total"]) * 4 + U * 4 + m["in_total"] * 4 + min(F, m["in_total"]) * 4
                 + F * (4 + 4) + m["node_lists"] * 4 + F * 4 + (0 if last else U * 16))
     return 0
+
+
+def compat_leg(indptr, indices, args, B, samples=384, workers=32):
+    """The drop-in path with the reference's own surface (PCIe inclusive): the native pybind11 module `cslicer`
+    used exactly like the reference's test_py.py -- cslicer(name, queue, workers, epochs, batch) then getSample() in
+    a loop, every sample's 3 x 4 BiPartites deep-copied into host `long` vectors -- at the reference's constants
+    (fanout 10/10/10, 4 parts, v % 4).  Never `value`: a host-list rate next to the device-resident one."""
+    import glob
+    import importlib.util
+    from cslicer import l0
+    hits = glob.glob(os.path.join(ROOT, "occ-gnn_amd", "pybind", "cslicer*.so"))
+    if not hits:
+        raise ImportError("native cslicer module not built")
+    spec = importlib.util.spec_from_file_location("cslicer_native_module", hits[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    root = os.path.join(os.environ.get("CSLICER_BENCH_CACHE", "/tmp/cslicer_bench_cache"), "l0")
+    name = "n%d_d%g_s%d" % (args.nodes, args.mean_deg, args.graph_seed)
+    if not os.path.exists(os.path.join(root, name, "meta.txt")):
+        l0.write_l0(os.path.join(root, name), indptr, indices)
+    t0 = time.perf_counter()
+    csl = mod.cslicer(name, 16, workers, 1, B, data_root=root)
+    t_load = time.perf_counter() - t0
+    n = min(samples, csl.getNoSamples())
+    s = csl.getSample()          # the first sample includes the mt19937 window fill
+    t0 = time.perf_counter()
+    for _ in range(n - 1):
+        s = csl.getSample()
+    dt = time.perf_counter() - t0
+    ids = sum(len(s.layers[l][g].in_nodes) for l in range(3) for g in range(4))
+    del s, csl
+    return {"samples_per_sec": (n - 1) / dt, "samples": n - 1, "workers": workers,
+            "config": "native pybind module `cslicer`, fanout 10/10/10, 4 parts (v % 4), minibatch %d, host `long` "
+                      "lists per sample (PCIe + deep copy inclusive)" % B,
+            "in_nodes_of_last_sample": ids, "constructor_seconds": t_load}
 
 
 def launch_plan(gpus, env):
@@ -471,12 +508,30 @@ def main():
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        tr.reset_units()
         tr.run(args.e2e_steps, first_batch=16)
         torch.cuda.synchronize()
         barrier()
         t_e2e = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)
+        work = tr.step_work(args.e2e_steps) if args.e2e_model == "sage" else None
         tr.close()
+        roof = None
+        if work is not None:
+            # this rank's algorithmic work per step over the step's wall time: what fraction of the chip's peaks the
+            # WHOLE step sustains (a step is GEMMs + HBM-bound aggregation + small kernels one after the other, so
+            # the two fractions add up to well below 1; the per-kernel split is profiles/r2_e2e/summary.md)
+            step_s = t_e2e / args.e2e_steps
+            roof = {
+                "gemm": {"bound": "mfma", "flops_per_step": work["gemm_flops"], "achieved": work["gemm_flops"] / step_s / 1e12,
+                         "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": work["gemm_flops"] / step_s / 1e12 / FP32_MFMA_PEAK_TFS},
+                "aggregation": {"bound": "hbm", "bytes_per_step": work["aggregation_bytes"],
+                                "achieved": work["aggregation_bytes"] / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": work["aggregation_bytes"] / step_s / 1e9 / HBM_PEAK_GBS},
+                "note": "algorithmic work of rank 0's step / the step's wall time; kernel-level split and GPU-busy "
+                        "fraction: profiles/r2_e2e/summary.md (rocprofv3 --kernel-trace --marker-trace)",
+            }
         return {
+            "roofline": roof,
             "iters_per_sec": args.e2e_steps / t_e2e, "ms_per_iter": 1e3 * t_e2e / args.e2e_steps,
             "steps": args.e2e_steps,
             "config": "split-parallel %s fanout %s, batch %d (global), %d part(s) = %d GPU(s), features %d, "
@@ -608,6 +663,11 @@ def main():
     if eng is not None:
         eng.close()
         eng = None
+    if rank == 0 and world == 1 and not args.no_compat:
+        try:
+            out["compat_path"] = compat_leg(indptr, indices, args, B)
+        except Exception as ex:   # optional evidence, never fatal
+            out["compat_path"] = {"error": repr(ex)[:200]}
     # The e2e leg runs LAST.  On several GPUs it is a job of RCCL collectives (all_to_all_single per layer +
     # gradient all-reduce) and runs under a watchdog: a collective that never completes, or a rank that raises,
     # must not take the slicer's result with it, and must not look like a success either.  Rank 0 then prints

@@ -85,6 +85,8 @@ class Trainer(object):
         self.overlap = overlap
         self.t_forward = self.t_slice = 0.0
         self.steps_done = 0
+        # units of the steps done (measurement only): per model layer k the output rows, source rows and edges
+        self.units = [{"rows": 0, "src": 0, "edges": 0} for _ in range(self.L)]
 
     def set_nodes(self, nodes):
         self.eng.set_nodes(nodes)
@@ -100,6 +102,12 @@ class Trainer(object):
         self.t_slice += time.perf_counter() - t0
         deep = slices[self.L - 1][self.rank]
         top = slices[0][self.rank]
+        for k in range(self.L):
+            sl = slices[self.L - 1 - k][self.rank]
+            u = self.units[k]
+            u["rows"] += sl.n_owned
+            u["src"] += sl.n_in
+            u["edges"] += sl.indices.numel()
         n_seeds = int(meta.n_seeds)
         fused = (not self.rank_path and self.kind == "sage" and self.P == 1 and self.feat.shape[1] % 4 == 0
                  and not splitgnn._NO_LOCAL_FUSE)
@@ -179,6 +187,30 @@ class Trainer(object):
                 losses.append(self._step(s, r & 1))
         torch.cuda.synchronize()
         return [float(x) for x in losses]
+
+    def reset_units(self):
+        for u in self.units:
+            u["rows"] = u["src"] = u["edges"] = 0
+
+    def step_work(self, steps):
+        """Algorithmic work of one training step on this rank, from the slices actually trained (fp32):
+        GEMM flops (forward, weight gradient, input gradient except for the deepest layer) and the bytes the
+        aggregation / elementwise kernels must move (csl_sage_cat: gathered source rows + operand store; its
+        backward: operand gradient + read-modify-write of the source gradient + its zero fill; ReLU backward +
+        bias sums: gradient in, mask in, gradient out)."""
+        flops = byts = 0.0
+        for k, (u, conv) in enumerate(zip(self.units, self.model.convs)):
+            if not hasattr(conv, "fc"):
+                return None
+            fout, fin2 = conv.fc.weight.shape
+            m, src, e = u["rows"] / steps, u["src"] / steps, u["edges"] / steps
+            flops += (2 if k == 0 else 3) * 2.0 * m * fin2 * fout
+            fin = fin2 // 2
+            byts += (m + e) * fin * 4 + m * fin2 * 4                     # operand: gathers + store
+            byts += 3 * m * fout * 4                                      # ReLU backward / bias sums
+            if k > 0:
+                byts += m * fin2 * 4 + 2 * (m + e) * fin * 4 + src * fin * 4   # source gradient
+        return {"gemm_flops": flops, "aggregation_bytes": byts}
 
     def report(self):
         n = max(self.steps_done, 1)

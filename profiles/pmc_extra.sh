@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmcx_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing --serial-rounds --e2e-steps 0"
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-compat --no-kernel-timing --serial-rounds --e2e-steps 0"
 [[ "${PMCX_LEGS:-wr l2 sq}" == *wr* ]] && rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum --kernel-trace --output-format csv -d $OUT/wr -- python3 $R/bench.py $ARGS > $OUT/wr.log 2>&1
 [[ "${PMCX_LEGS:-wr l2 sq}" == *l2* ]] && rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_WRITE_REQ_sum --kernel-trace --output-format csv -d $OUT/l2 -- python3 $R/bench.py $ARGS > $OUT/l2.log 2>&1
 [[ "${PMCX_LEGS:-wr l2 sq}" == *sq* ]] && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/sq -- python3 $R/bench.py $ARGS > $OUT/sq.log 2>&1

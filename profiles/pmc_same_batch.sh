@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_same_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --serial-rounds --e2e-steps 0"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-compat --no-kernel-timing --serial-rounds --e2e-steps 0"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/normal -- python3 $R/bench.py $ARGS > $OUT/normal.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/same -- python3 $R/bench.py $ARGS --same-batch > $OUT/same.log 2>&1
 python3 - $OUT <<'PY'

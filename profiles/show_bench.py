@@ -18,3 +18,17 @@ if "path_roofline" in d:
 if "cpu_baseline" in d:
     c = d["cpu_baseline"]
     print("  cpu: %.3f Gedges/s on %d cores (%s)" % (c["value"] / 1e9, c["cores"], c["kind"]))
+if "compat_path" in d:
+    c = d["compat_path"]
+    print("  compat (host lists):", ("%.0f samples/s" % c["samples_per_sec"]) if "samples_per_sec" in c else c)
+if d.get("e2e"):
+    e = d["e2e"]
+    if "iters_per_sec" in e:
+        print("  e2e: %.0f it/s (%.3f ms)" % (e["iters_per_sec"], e["ms_per_iter"]))
+        r = e.get("roofline")
+        if r:
+            print("    GEMM %.1f TF/s (%.0f%% of %.0f), aggregation %.0f GB/s (%.0f%% of 8 TB/s) over the whole step" % (
+                r["gemm"]["achieved"], 100 * r["gemm"]["frac"], r["gemm"]["peak"], r["aggregation"]["achieved"],
+                100 * r["aggregation"]["frac"]))
+    else:
+        print("  e2e:", e)

@@ -19,7 +19,7 @@ else
     name=${v%%:*}
     for rep in $(seq $REPS); do
       echo -n "$name: "
-      CSLICER_LIB=$D/lib_$name.so python3 $R/bench.py --no-cpu-baseline $SWEEP_BENCH_ARGS --e2e-steps 0 --steps 30 --warmup 5 2>/dev/null | python3 $R/profiles/show_bench.py | ${SWEEP_FILTER:-head -1}
+      CSLICER_LIB=$D/lib_$name.so python3 $R/bench.py --no-cpu-baseline --no-compat $SWEEP_BENCH_ARGS --e2e-steps 0 --steps 30 --warmup 5 2>/dev/null | python3 $R/profiles/show_bench.py | ${SWEEP_FILTER:-head -1}
     done
   done
 fi
