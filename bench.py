@@ -169,7 +169,7 @@ def compat_leg(indptr, indices, args, B, samples=384, workers=32):
     hits = glob.glob(os.path.join(ROOT, "occ-gnn_amd", "pybind", "cslicer*.so"))
     if not hits:
         raise ImportError("native cslicer module not built")
-    spec = importlib.util.spec_from_file_location("cslicer_native_module", hits[0])
+    spec = importlib.util.spec_from_file_location("cslicer", hits[0])   # (PyInit_cslicer; not registered in sys.modules)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     root = os.path.join(os.environ.get("CSLICER_BENCH_CACHE", "/tmp/cslicer_bench_cache"), "l0")
