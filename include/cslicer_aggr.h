@@ -106,14 +106,13 @@ int csl_softmax_ce_f32(const float* logits, int64_t ldl, int64_t n, int32_t C, c
                        void* stream);
 
 /* Transposed slice: for every SOURCE row u of a slice CSR (indptr/indices over n_rows destination rows, sources in
- * [0, n_src)): tptr[u] .. tptr[u+1] (n_src + 1 entries) index trow (destination row of each edge out of u) and tw
- * (1 / max(deg(row), 1)); inv[u] = 1 + the destination row whose self source is u (self_ids), or 0.
- * work: csl_csr_transpose_work(n_src) ints of scratch.  Built on the fly (count, two-level scan, fill): the order
- * of a source's edges in trow is not deterministic. */
-int64_t csl_csr_transpose_work(int64_t n_src);
+ * [0, n_src)): tptr[u] .. tptr[u+1] index trow (destination row of each edge out of u) and tw (1 / max(deg(row), 1));
+ * work[n_src + u] = 1 + the destination row whose self source is u (self_ids), or 0.  work: 2 * n_src ints (the
+ * first n_src are scratch).  Built on the fly (count, one-block scan, fill): the order of a source's edges in
+ * trow is not deterministic. */
 int csl_csr_transpose_i32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, int64_t n_rows,
-                          int64_t n_src, int64_t n_edges, int32_t* tptr, int32_t* trow, float* tw, int32_t* inv,
-                          int32_t* work, void* stream);
+                          int64_t n_src, int64_t n_edges, int32_t* tptr, int32_t* trow, float* tw, int32_t* work,
+                          void* stream);
 
 /* Backward of csl_sage_cat_f32 (CSR form) as a gather over the transposed slice, with the ReLU mask of the layer
  * below, the row padding of its GEMM operand and its bias column sums in the same pass:

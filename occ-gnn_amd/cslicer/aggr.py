@@ -15,7 +15,7 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_scatter_add_rows_f32", "csl_div_rows_f32", "csl_gat_fwd_f32", "csl_gat_bwd_f32",
            "csl_sage_cat_f32", "csl_sage_cat_bwd_f32", "csl_relu_bwd_colsum_f32", "csl_softmax_ce_f32",
            "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch", "csl_adam_f32", "csl_csr_transpose_i32",
-           "csl_sage_cat_bwd_csc_f32", "csl_sage_cat_bwd_csc_scratch", "csl_csr_transpose_work"]
+           "csl_sage_cat_bwd_csc_f32", "csl_sage_cat_bwd_csc_scratch"]
 _ready = False
 
 
@@ -41,9 +41,7 @@ def _lib():
         L.csl_softmax_ce_scratch.argtypes = [i64]
         L.csl_softmax_ce_scratch.restype = i64
         L.csl_adam_f32.argtypes = [i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, vp]
-        L.csl_csr_transpose_i32.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
-        L.csl_csr_transpose_work.argtypes = [i64]
-        L.csl_csr_transpose_work.restype = i64
+        L.csl_csr_transpose_i32.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp]
         L.csl_sage_cat_bwd_csc_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, vp, i64, vp, vp, i32, vp]
         L.csl_sage_cat_bwd_csc_scratch.argtypes = [i64, i32]
         L.csl_sage_cat_bwd_csc_scratch.restype = i64
@@ -198,17 +196,14 @@ def csr_transpose(indptr, indices, self_ids, n_rows, n_src):
     device tensors; see cslicer_aggr.h."""
     dev = indptr.device
     E = int(indices.numel())
-    L = _lib()
-    nw = int(L.csl_csr_transpose_work(n_src))
-    ints = torch.empty((2 * n_src + 1 + max(E, 1) + nw,), dtype=torch.int32, device=dev)   # tptr | inv | trow | work
-    tptr, inv = ints[:n_src + 1], ints[n_src + 1:2 * n_src + 1]
-    trow, work = ints[2 * n_src + 1:2 * n_src + 1 + max(E, 1)], ints[2 * n_src + 1 + max(E, 1):]
+    ints = torch.empty((3 * n_src + 1 + max(E, 1),), dtype=torch.int32, device=dev)   # tptr | work (2 n_src) | trow
+    tptr, work, trow = ints[:n_src + 1], ints[n_src + 1:3 * n_src + 1], ints[3 * n_src + 1:]
     tw = torch.empty((max(E, 1),), dtype=torch.float32, device=dev)
-    _chk(L.csl_csr_transpose_i32(_p(_i32(indptr)), _p(_i32(indices)), _p(_i32(self_ids)), n_rows, n_src, E,
-                                 C.c_void_p(tptr.data_ptr()), C.c_void_p(trow.data_ptr()), C.c_void_p(tw.data_ptr()),
-                                 C.c_void_p(inv.data_ptr()), C.c_void_p(work.data_ptr()), _stream()),
+    _chk(_lib().csl_csr_transpose_i32(_p(_i32(indptr)), _p(_i32(indices)), _p(_i32(self_ids)), n_rows, n_src, E,
+                                      C.c_void_p(tptr.data_ptr()), C.c_void_p(trow.data_ptr()),
+                                      C.c_void_p(tw.data_ptr()), C.c_void_p(work.data_ptr()), _stream()),
          "csl_csr_transpose_i32")
-    return tptr, trow, tw, inv
+    return tptr, trow, tw, work[n_src:]
 
 
 def sage_cat_bwd_csc(tr, gcat, y, n_src, n_pad):

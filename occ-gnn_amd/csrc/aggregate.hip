@@ -536,54 +536,52 @@ __global__ __launch_bounds__(BLK) void k_csc_count(const int* __restrict__ indpt
   if (sid >= 0) inv[sid] = (int)r + 1;
   for (long long e = indptr[r]; e < indptr[r + 1]; e++) atomicAdd(&cnt[indices[e]], 1);
 }
-// Scan of the per-source counts in two levels without a second launch for the upper one: block b scans its
-// CSC_T counts (coalesced, one per thread) into `loc`, then adds its total to base[k] of every LATER block k
-// (nblk^2 / 2 atomics on nblk words: a few thousand).  tptr[u] = loc[u] + base[u / CSC_T] is assembled by the
-// fill pass below (and used by it before that, on the fly).
+// one block: tptr = exclusive scan of cnt (n + 1 entries), cnt becomes the fill cursor (= tptr)
 constexpr int CSC_T = 1024;
-__global__ __launch_bounds__(CSC_T) void k_csc_scan(const int* __restrict__ cnt, long long n, int* __restrict__ loc,
-                                                    int* base) {
+__global__ __launch_bounds__(CSC_T) void k_csc_scan(int* cnt, long long n, int* __restrict__ tptr) {
   __shared__ int s_w[CSC_T / 64];
+  __shared__ int s_run;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const long long i = (long long)blockIdx.x * CSC_T + t;
-  const int x = i < n ? cnt[i] : 0;
-  int incl = x;
+  const long long chunk = (n + CSC_T - 1) / CSC_T;
+  const long long lo = (long long)t * chunk < n ? (long long)t * chunk : n;
+  const long long hi = lo + chunk < n ? lo + chunk : n;
+  int sum = 0;
+  for (long long i = lo; i < hi; i++) sum += cnt[i];
+  int incl = sum;
   for (int o = 1; o < 64; o <<= 1) {
     const int y = __shfl_up(incl, o);
     if (lane >= o) incl += y;
   }
   if (lane == 63) s_w[w] = incl;
   __syncthreads();
-  int before = 0, total = 0;
-  for (int k = 0; k < CSC_T / 64; k++) {
-    const int v = s_w[k];
-    if (k < w) before += v;
-    total += v;
+  if (t == 0) {
+    int run = 0;
+    for (int k = 0; k < CSC_T / 64; k++) {
+      const int x = s_w[k];
+      s_w[k] = run;
+      run += x;
+    }
+    s_run = run;
   }
-  if (i < n) loc[i] = before + incl - x;
-  if (total)
-    for (long long k = (long long)blockIdx.x + 1 + t; k < (long long)gridDim.x; k += CSC_T) atomicAdd(&base[k], total);
+  __syncthreads();
+  int run = s_w[w] + incl - sum;
+  for (long long i = lo; i < hi; i++) {
+    const int c = cnt[i];
+    tptr[i] = run;
+    cnt[i] = run;
+    run += c;
+  }
+  if (t == 0) tptr[n] = s_run;
 }
-// blocks [0, row_blocks): one thread per destination row places its edges; the rest: one thread per source writes
-// the final tptr (n_src + 1 entries)
 __global__ __launch_bounds__(BLK) void k_csc_fill(const int* __restrict__ indptr, const int* __restrict__ indices,
-                                                  long long n_rows, long long n_src, unsigned row_blocks,
-                                                  const int* __restrict__ loc, const int* __restrict__ base, int* cur,
-                                                  int* __restrict__ tptr, int* __restrict__ trow, float* __restrict__ tw,
-                                                  int n_edges) {
-  if (blockIdx.x >= row_blocks) {
-    const long long u = (long long)(blockIdx.x - row_blocks) * BLK + threadIdx.x;
-    if (u < n_src) tptr[u] = loc[u] + base[u / CSC_T];
-    if (u == n_src) tptr[u] = n_edges;
-    return;
-  }
+                                                  long long n_rows, int* cur, int* __restrict__ trow,
+                                                  float* __restrict__ tw) {
   const long long r = (long long)blockIdx.x * BLK + threadIdx.x;
   if (r >= n_rows) return;
   const long long e0 = indptr[r], e1 = indptr[r + 1];
   const float w = 1.0f / (float)(e1 - e0 > 1 ? e1 - e0 : 1);
   for (long long e = e0; e < e1; e++) {
-    const int u = indices[e];
-    const int pos = loc[u] + base[u / CSC_T] + atomicAdd(&cur[u], 1);
+    const int pos = atomicAdd(&cur[indices[e]], 1);
     trow[pos] = (int)r;
     tw[pos] = w;
   }
@@ -898,34 +896,21 @@ int csl_adam_f32(int32_t count, float* const* params, const float* const* grads,
   return done();
 }
 
-int64_t csl_csr_transpose_work(int64_t n_src) {
-  // cnt | cur | inv | base (zeroed together), then loc
-  return 4 * n_src + (n_src + CSC_T - 1) / CSC_T + 1;
-}
-
 int csl_csr_transpose_i32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, int64_t n_rows,
-                          int64_t n_src, int64_t n_edges, int32_t* tptr, int32_t* trow, float* tw, int32_t* inv,
-                          int32_t* work, void* stream) {
-  if (n_rows < 0 || n_src < 0 || n_edges < 0 || n_edges >= (1ll << 31) || !tptr || (n_src > 0 && (!work || !inv)))
-    return CSL_E_INVALID;
+                          int64_t n_src, int64_t n_edges, int32_t* tptr, int32_t* trow, float* tw, int32_t* work,
+                          void* stream) {
+  if (n_rows < 0 || n_src < 0 || n_edges < 0 || !tptr || (n_src > 0 && !work)) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  const long long nblk = (n_src + CSC_T - 1) / CSC_T;
-  int32_t* cnt = work;
-  int32_t* cur = work + n_src;
-  int32_t* base = work + 2 * n_src;          // nblk + 1 words
-  int32_t* loc = work + 2 * n_src + nblk + 1;  // not zeroed: every entry is written
-  if (hipMemsetAsync(work, 0, sizeof(int32_t) * (size_t)(2 * n_src + nblk + 1), st) != hipSuccess) return CSL_E_HIP;
-  if (n_src > 0 && hipMemsetAsync(inv, 0, sizeof(int32_t) * (size_t)n_src, st) != hipSuccess) return CSL_E_HIP;
+  if (n_src > 0 && hipMemsetAsync(work, 0, sizeof(int32_t) * 2 * (size_t)n_src, st) != hipSuccess) return CSL_E_HIP;
   if (n_rows > 0) {
     if (!indptr || !self_ids || (n_edges > 0 && (!indices || !trow || !tw))) return CSL_E_INVALID;
     hipLaunchKernelGGL(k_csc_count, dim3((unsigned)((n_rows + BLK - 1) / BLK)), dim3(BLK), 0, st, indptr, indices, self_ids,
-                       (long long)n_rows, cnt, inv);
+                       (long long)n_rows, work, work + n_src);
   }
-  if (nblk > 0) hipLaunchKernelGGL(k_csc_scan, dim3((unsigned)nblk), dim3(CSC_T), 0, st, cnt, (long long)n_src, loc, base);
-  const unsigned row_blocks = (unsigned)((n_rows + BLK - 1) / BLK);
-  const unsigned src_blocks = (unsigned)((n_src + 1 + BLK - 1) / BLK);
-  hipLaunchKernelGGL(k_csc_fill, dim3(row_blocks + src_blocks), dim3(BLK), 0, st, indptr, indices, (long long)n_rows,
-                     (long long)n_src, row_blocks, loc, base, cur, tptr, trow, tw, (int)n_edges);
+  hipLaunchKernelGGL(k_csc_scan, dim3(1), dim3(CSC_T), 0, st, work, (long long)n_src, tptr);
+  if (n_rows > 0 && n_edges > 0)
+    hipLaunchKernelGGL(k_csc_fill, dim3((unsigned)((n_rows + BLK - 1) / BLK)), dim3(BLK), 0, st, indptr, indices,
+                       (long long)n_rows, work, trow, tw);
   return done();
 }
 
