@@ -105,25 +105,6 @@ int csl_softmax_ce_f32(const float* logits, int64_t ldl, int64_t n, int32_t C, c
                        const int64_t* labels, float scale, float* loss, float* grad, int64_t ldgr, float* scratch,
                        void* stream);
 
-/* Transposed slice: for every SOURCE row u of a slice CSR (indptr/indices over n_rows destination rows, sources in
- * [0, n_src)): tptr[u] .. tptr[u+1] index trow (destination row of each edge out of u) and tw (1 / max(deg(row), 1));
- * work[n_src + u] = 1 + the destination row whose self source is u (self_ids), or 0.  work: 2 * n_src ints (the
- * first n_src are scratch).  Built on the fly (count, one-block scan, fill): the order of a source's edges in
- * trow is not deterministic. */
-int csl_csr_transpose_i32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, int64_t n_rows,
-                          int64_t n_src, int64_t n_edges, int32_t* tptr, int32_t* trow, float* tw, int32_t* work,
-                          void* stream);
-
-/* Backward of csl_sage_cat_f32 (CSR form) as a gather over the transposed slice, with the ReLU mask of the layer
- * below, the row padding of its GEMM operand and its bias column sums in the same pass:
- *   out[u, :] = mask_u .* ( gcat[inv[u]-1, 0:H) + sum_j tw[j] * gcat[trow[j], H:2H) ),  mask_u = y ? y[u, :] > 0 : 1
- * for u < n_src, zero rows up to n_pad; colsum[c] = sum_u out[u, c].  No atomics, nothing to pre-zero.
- * scratch: csl_sage_cat_bwd_csc_scratch(n_pad, H) floats.  H % 4 == 0. */
-int64_t csl_sage_cat_bwd_csc_scratch(int64_t n_pad, int32_t H);
-int csl_sage_cat_bwd_csc_f32(const int32_t* tptr, const int32_t* trow, const float* tw, const int32_t* inv,
-                             const float* gcat, int64_t ldg, const float* y, int64_t ldy, int64_t n_src, int64_t n_pad,
-                             float* out, int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream);
-
 /* torch.optim.Adam's update (python/train.py:83; no weight decay, no amsgrad) for up to 24 parameter tensors in one
  * launch.  params / grads / exp_avg / exp_avg_sq: HOST arrays of `count` device pointers, numel[t] elements each;
  * step = 1 for the first update (bias corrections 1 - beta^step are computed on the host). */

@@ -14,8 +14,7 @@ from . import _abi
 SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_scatter_add_rows_f32", "csl_div_rows_f32", "csl_gat_fwd_f32", "csl_gat_bwd_f32",
            "csl_sage_cat_f32", "csl_sage_cat_bwd_f32", "csl_relu_bwd_colsum_f32", "csl_softmax_ce_f32",
-           "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch", "csl_adam_f32", "csl_csr_transpose_i32",
-           "csl_sage_cat_bwd_csc_f32", "csl_sage_cat_bwd_csc_scratch"]
+           "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch", "csl_adam_f32"]
 _ready = False
 
 
@@ -41,10 +40,6 @@ def _lib():
         L.csl_softmax_ce_scratch.argtypes = [i64]
         L.csl_softmax_ce_scratch.restype = i64
         L.csl_adam_f32.argtypes = [i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, vp]
-        L.csl_csr_transpose_i32.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp]
-        L.csl_sage_cat_bwd_csc_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, i64, i64, i64, vp, i64, vp, vp, i32, vp]
-        L.csl_sage_cat_bwd_csc_scratch.argtypes = [i64, i32]
-        L.csl_sage_cat_bwd_csc_scratch.restype = i64
         _ready = True
     return L
 
@@ -188,38 +183,6 @@ def relu_bwd_colsum(g, y, n, n_pad):
                                    y.stride(0) if y is not None else 0, n, n_pad, _p(out), out.stride(0),
                                    C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr() + 4 * H), H, _stream()),
          "csl_relu_bwd_colsum_f32")
-    return out, buf[:H]
-
-
-def csr_transpose(indptr, indices, self_ids, n_rows, n_src):
-    """The slice by SOURCE (csl_csr_transpose_i32): (tptr [n_src+1], trow [E], tw [E], inv [n_src]) int32/float32
-    device tensors; see cslicer_aggr.h."""
-    dev = indptr.device
-    E = int(indices.numel())
-    ints = torch.empty((3 * n_src + 1 + max(E, 1),), dtype=torch.int32, device=dev)   # tptr | work (2 n_src) | trow
-    tptr, work, trow = ints[:n_src + 1], ints[n_src + 1:3 * n_src + 1], ints[3 * n_src + 1:]
-    tw = torch.empty((max(E, 1),), dtype=torch.float32, device=dev)
-    _chk(_lib().csl_csr_transpose_i32(_p(_i32(indptr)), _p(_i32(indices)), _p(_i32(self_ids)), n_rows, n_src, E,
-                                      C.c_void_p(tptr.data_ptr()), C.c_void_p(trow.data_ptr()),
-                                      C.c_void_p(tw.data_ptr()), C.c_void_p(work.data_ptr()), _stream()),
-         "csl_csr_transpose_i32")
-    return tptr, trow, tw, work[n_src:]
-
-
-def sage_cat_bwd_csc(tr, gcat, y, n_src, n_pad):
-    """Gradient of sage_cat's CSR form w.r.t. x as a gather over the transposed slice `tr` (csr_transpose), masked
-    by y > 0 (y None: unmasked), rows padded with zeros to n_pad; returns (out [n_pad, H], column sums [H])."""
-    tptr, trow, tw, inv = tr
-    gcat = _f32(gcat)
-    H = gcat.shape[1] // 2
-    out = torch.empty((n_pad, H), dtype=torch.float32, device=gcat.device)
-    L = _lib()
-    buf = torch.empty((H + max(int(L.csl_sage_cat_bwd_csc_scratch(n_pad, H)), 1),), dtype=torch.float32,
-                      device=gcat.device)
-    _chk(L.csl_sage_cat_bwd_csc_f32(_p(tptr), _p(trow), _p(tw), _p(inv), _p(gcat), gcat.stride(0),
-                                    _p(y) if y is not None else C.c_void_p(0), y.stride(0) if y is not None else 0,
-                                    n_src, n_pad, _p(out), out.stride(0), C.c_void_p(buf.data_ptr()),
-                                    C.c_void_p(buf.data_ptr() + 4 * H), H, _stream()), "csl_sage_cat_bwd_csc_f32")
     return out, buf[:H]
 
 

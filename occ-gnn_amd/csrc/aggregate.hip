@@ -518,134 +518,6 @@ __global__ __launch_bounds__(BLK) void k_softmax_ce(const float* __restrict__ lo
   if (threadIdx.x == 0) partial[blockIdx.x] = s_l[0] + s_l[1] + s_l[2] + s_l[3];
 }
 
-// ---- transposed slice (by source) and the atomics-free backward of k_sage_cat ---------------------------------
-// The forward gathers source rows per destination (CSR by destination, as the slicer emits it).  Its backward
-// scatters: with fp32 atomics into a zeroed buffer (k_sage_cat_bwd: 82 MB of zero fill + 120 MB of L2 atomics
-// for the middle layer of the headline model), or -- here -- as a GATHER over the transposed structure, built on
-// the fly in three small passes (count, scan, fill).  Every source-gradient row is then written exactly once, so
-// the ReLU mask of the layer below, the row padding of its GEMM operand and its bias column sums ride on the same
-// pass (k_relu_bwd_colsum's job): one kernel instead of memset + atomics + mask/sum pass.
-//   cnt[u]   = #edges with source u            inv[u] = 1 + the row whose SELF source is u, or 0
-//   tptr     = exclusive scan of cnt           trow/tw[tptr[u] ..] = the destination rows of u's edges / 1/deg(row)
-__global__ __launch_bounds__(BLK) void k_csc_count(const int* __restrict__ indptr, const int* __restrict__ indices,
-                                                   const int* __restrict__ self_ids, long long n_rows, int* cnt,
-                                                   int* __restrict__ inv) {
-  const long long r = (long long)blockIdx.x * BLK + threadIdx.x;
-  if (r >= n_rows) return;
-  const int sid = self_ids[r];
-  if (sid >= 0) inv[sid] = (int)r + 1;
-  for (long long e = indptr[r]; e < indptr[r + 1]; e++) atomicAdd(&cnt[indices[e]], 1);
-}
-// one block: tptr = exclusive scan of cnt (n + 1 entries), cnt becomes the fill cursor (= tptr)
-constexpr int CSC_T = 1024;
-__global__ __launch_bounds__(CSC_T) void k_csc_scan(int* cnt, long long n, int* __restrict__ tptr) {
-  __shared__ int s_w[CSC_T / 64];
-  __shared__ int s_run;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const long long chunk = (n + CSC_T - 1) / CSC_T;
-  const long long lo = (long long)t * chunk < n ? (long long)t * chunk : n;
-  const long long hi = lo + chunk < n ? lo + chunk : n;
-  int sum = 0;
-  for (long long i = lo; i < hi; i++) sum += cnt[i];
-  int incl = sum;
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y = __shfl_up(incl, o);
-    if (lane >= o) incl += y;
-  }
-  if (lane == 63) s_w[w] = incl;
-  __syncthreads();
-  if (t == 0) {
-    int run = 0;
-    for (int k = 0; k < CSC_T / 64; k++) {
-      const int x = s_w[k];
-      s_w[k] = run;
-      run += x;
-    }
-    s_run = run;
-  }
-  __syncthreads();
-  int run = s_w[w] + incl - sum;
-  for (long long i = lo; i < hi; i++) {
-    const int c = cnt[i];
-    tptr[i] = run;
-    cnt[i] = run;
-    run += c;
-  }
-  if (t == 0) tptr[n] = s_run;
-}
-__global__ __launch_bounds__(BLK) void k_csc_fill(const int* __restrict__ indptr, const int* __restrict__ indices,
-                                                  long long n_rows, int* cur, int* __restrict__ trow,
-                                                  float* __restrict__ tw) {
-  const long long r = (long long)blockIdx.x * BLK + threadIdx.x;
-  if (r >= n_rows) return;
-  const long long e0 = indptr[r], e1 = indptr[r + 1];
-  const float w = 1.0f / (float)(e1 - e0 > 1 ? e1 - e0 : 1);
-  for (long long e = e0; e < e1; e++) {
-    const int pos = atomicAdd(&cur[indices[e]], 1);
-    trow[pos] = (int)r;
-    tw[pos] = w;
-  }
-}
-// out[u, :] = mask_u .* ( gcat[inv[u]-1, 0:H) + sum_j tw[j] * gcat[trow[j], H:2H) ),  j over u's transposed edges;
-// mask_u = y ? (y[u, :] > 0) : 1; rows [n_src, n_pad) zero; per-block column sums to `partial` (k_colsum_finish).
-constexpr int CSCB_G = 16;  // lanes per source row: 16 rows in flight per block, four float4 columns per lane at H = 256
-__global__ __launch_bounds__(BLK) void k_sage_cat_bwd_csc(const int* __restrict__ tptr, const int* __restrict__ trow,
-                                                          const float* __restrict__ tw, const int* __restrict__ inv,
-                                                          const float* __restrict__ gcat, long long ldg,
-                                                          const float* __restrict__ y, long long ldy, long long n_src,
-                                                          long long n_pad, float* __restrict__ out, long long ldo,
-                                                          float* __restrict__ partial, int H, long long rows_per_block) {
-  constexpr int G = CSCB_G, RPB = BLK / G;
-  const int lane = threadIdx.x % G, sub = threadIdx.x / G;
-  const long long r0 = (long long)blockIdx.x * rows_per_block;
-  const long long r_end = r0 + rows_per_block < n_pad ? r0 + rows_per_block : n_pad;
-  __shared__ float s_sum[BLK * 4];
-  for (int c0 = 0; c0 < H; c0 += G * 4) {  // block-uniform
-    const int c = c0 + lane * 4;
-    float4 colacc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long long u = r0 + sub; u < r_end; u += RPB) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (u < n_src && c < H) {
-        const int iv = inv[u];
-        const int j0 = tptr[u], j1 = tptr[u + 1];
-        if (iv) acc = *reinterpret_cast<const float4*>(gcat + (long long)(iv - 1) * ldg + c);
-        int j = j0;
-        for (; j + 2 <= j1; j += 2) {  // two contributions in flight
-          const int ra = trow[j], rb = trow[j + 1];
-          const float wa = tw[j], wb = tw[j + 1];
-          const float4 va = *reinterpret_cast<const float4*>(gcat + (long long)ra * ldg + H + c);
-          const float4 vb = *reinterpret_cast<const float4*>(gcat + (long long)rb * ldg + H + c);
-          acc.x += wa * va.x, acc.y += wa * va.y, acc.z += wa * va.z, acc.w += wa * va.w;
-          acc.x += wb * vb.x, acc.y += wb * vb.y, acc.z += wb * vb.z, acc.w += wb * vb.w;
-        }
-        if (j < j1) {
-          const float wa = tw[j];
-          const float4 va = *reinterpret_cast<const float4*>(gcat + (long long)trow[j] * ldg + H + c);
-          acc.x += wa * va.x, acc.y += wa * va.y, acc.z += wa * va.z, acc.w += wa * va.w;
-        }
-        if (y) {
-          const float4 a = *reinterpret_cast<const float4*>(y + u * ldy + c);
-          acc.x = a.x > 0.f ? acc.x : 0.f, acc.y = a.y > 0.f ? acc.y : 0.f, acc.z = a.z > 0.f ? acc.z : 0.f, acc.w = a.w > 0.f ? acc.w : 0.f;
-        }
-        add4(colacc, acc);
-      }
-      if (c < H) *reinterpret_cast<float4*>(out + u * ldo + c) = acc;
-    }
-    __syncthreads();
-    reinterpret_cast<float4*>(s_sum)[threadIdx.x] = colacc;
-    __syncthreads();
-    if (sub == 0 && c < H) {
-      for (int k = 1; k < RPB; k++) add4(colacc, reinterpret_cast<float4*>(s_sum)[k * G + lane]);
-      *reinterpret_cast<float4*>(partial + (long long)blockIdx.x * H + c) = colacc;
-    }
-  }
-}
-__host__ __device__ inline long long cscb_rows(long long n_pad) {
-  long long r = 64;
-  while ((n_pad + r - 1) / r > 2048) r *= 2;
-  return r;
-}
-
 // ---- Adam (python/train.py:83 torch.optim.Adam, no weight decay, no amsgrad) over every parameter tensor of the
 // model in ONE launch: the model has six small tensors, the library's for-each form is 1-8 launches of 20-40 us.
 //   m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
@@ -893,48 +765,6 @@ int csl_adam_f32(int32_t count, float* const* params, const float* const* grads,
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(BLK), 0, (hipStream_t)stream, a, beta1, beta2,
                      (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps);
-  return done();
-}
-
-int csl_csr_transpose_i32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, int64_t n_rows,
-                          int64_t n_src, int64_t n_edges, int32_t* tptr, int32_t* trow, float* tw, int32_t* work,
-                          void* stream) {
-  if (n_rows < 0 || n_src < 0 || n_edges < 0 || !tptr || (n_src > 0 && !work)) return CSL_E_INVALID;
-  hipStream_t st = (hipStream_t)stream;
-  if (n_src > 0 && hipMemsetAsync(work, 0, sizeof(int32_t) * 2 * (size_t)n_src, st) != hipSuccess) return CSL_E_HIP;
-  if (n_rows > 0) {
-    if (!indptr || !self_ids || (n_edges > 0 && (!indices || !trow || !tw))) return CSL_E_INVALID;
-    hipLaunchKernelGGL(k_csc_count, dim3((unsigned)((n_rows + BLK - 1) / BLK)), dim3(BLK), 0, st, indptr, indices, self_ids,
-                       (long long)n_rows, work, work + n_src);
-  }
-  hipLaunchKernelGGL(k_csc_scan, dim3(1), dim3(CSC_T), 0, st, work, (long long)n_src, tptr);
-  if (n_rows > 0 && n_edges > 0)
-    hipLaunchKernelGGL(k_csc_fill, dim3((unsigned)((n_rows + BLK - 1) / BLK)), dim3(BLK), 0, st, indptr, indices,
-                       (long long)n_rows, work, trow, tw);
-  return done();
-}
-
-int64_t csl_sage_cat_bwd_csc_scratch(int64_t n_pad, int32_t H) {
-  const long long rpb = cscb_rows(n_pad);
-  return ((n_pad + rpb - 1) / rpb) * (int64_t)(H > 0 ? H : 0);
-}
-
-int csl_sage_cat_bwd_csc_f32(const int32_t* tptr, const int32_t* trow, const float* tw, const int32_t* inv,
-                             const float* gcat, int64_t ldg, const float* y, int64_t ldy, int64_t n_src, int64_t n_pad,
-                             float* out, int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream) {
-  if (n_src < 0 || n_pad < n_src || H < 4 || H % 4 != 0 || !colsum) return CSL_E_INVALID;
-  hipStream_t st = (hipStream_t)stream;
-  const long long rpb = cscb_rows(n_pad);
-  const long long blocks = (n_pad + rpb - 1) / rpb;
-  if (blocks > 0) {
-    if (!out || !scratch || ldo < H || ldo % 4 != 0 || !aligned16(out)) return CSL_E_INVALID;
-    if (n_src > 0 && (!tptr || !inv || !gcat || ldg < 2 * (int64_t)H || ldg % 4 != 0 || !aligned16(gcat))) return CSL_E_INVALID;
-    if (y && (ldy < H || ldy % 4 != 0 || !aligned16(y))) return CSL_E_INVALID;
-    hipLaunchKernelGGL(k_sage_cat_bwd_csc, dim3((unsigned)blocks), dim3(BLK), 0, st, tptr, trow, tw, inv, gcat,
-                       (long long)ldg, y, (long long)ldy, (long long)n_src, (long long)n_pad, out, (long long)ldo, scratch,
-                       (int)H, rpb);
-  }
-  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((H + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, (int)H, colsum);
   return done();
 }
 

@@ -378,64 +378,3 @@ def test_adam_matches_torch(mods):
         ob.step()
     for a_, b_ in zip(pa, pb):
         torch.testing.assert_close(a_.detach(), b_.detach(), rtol=1e-5, atol=1e-6)
-
-
-@pytest.mark.parametrize("H,masked", [(256, True), (100, False), (32, True)])
-def test_transposed_gather_backward_matches_the_atomic_one(mods, H, masked):
-    """csl_csr_transpose_i32 + csl_sage_cat_bwd_csc_f32 (gather over the slice by source; mask, padding and bias
-    sums in the same pass) against csl_sage_cat_bwd_f32 (atomics) + csl_relu_bwd_colsum_f32 and against torch."""
-    _, aggr, _ = mods
-    rng = np.random.default_rng(H + 1)
-    n, n_src, n_pad = 3000, 5000, 8192
-    indptr, indices = _rand_csr(n, n_src, 14, rng)
-    self_ids = rng.permutation(n_src)[:n].astype(np.int32)
-    self_ids[::13] = -1
-    ip, ix, si = (torch.from_numpy(a).int().cuda() for a in (indptr, indices, self_ids))
-    gcat = torch.randn(n + 40, 2 * H, device="cuda")
-    y = torch.randn(n_pad, H, device="cuda") if masked else None
-    tr = aggr.csr_transpose(ip, ix, si, n, n_src)
-    tptr, trow, tw, inv = tr
-    # the transposed structure itself
-    assert int(tptr[-1]) == indices.shape[0] and bool((tptr[1:] >= tptr[:-1]).all())
-    cnt = np.bincount(indices, minlength=n_src)
-    np.testing.assert_array_equal((tptr[1:] - tptr[:-1]).cpu().numpy(), cnt)
-    rows_of_edge = np.repeat(np.arange(n), np.diff(indptr))
-    for u in rng.choice(n_src, size=200, replace=False):
-        got = np.sort(trow[int(tptr[u]):int(tptr[u + 1])].cpu().numpy())
-        np.testing.assert_array_equal(got, np.sort(rows_of_edge[indices == u]))
-    inv_ref = np.zeros(n_src, dtype=np.int64)
-    inv_ref[self_ids[self_ids >= 0]] = np.flatnonzero(self_ids >= 0) + 1
-    np.testing.assert_array_equal(inv.cpu().numpy(), inv_ref)
-    out, cs = aggr.sage_cat_bwd_csc(tr, gcat, y, n_src, n_pad)
-    ref = aggr.sage_cat_bwd(ip, ix, si, gcat, n, n_src)
-    ref2, cs2 = aggr.relu_bwd_colsum(ref, y, n_src, n_pad)
-    assert out.shape == (n_pad, H) and float(out[n_src:].abs().sum()) == 0.0
-    torch.testing.assert_close(out, ref2, rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(cs, cs2, rtol=1e-4, atol=1e-3)
-
-
-def test_model_level_node_matches_layerwise_nodes(mods, monkeypatch):
-    """DistSAGEModel.forward_local as ONE autograd node (_SageModelLocal: transposed-gather backward fused across
-    layers) == one node per layer (_SageLayerLocal: atomic scatter backward): logits and every weight gradient."""
-    abi, aggr, sg = mods
-    from cslicer import l0
-    torch.manual_seed(4)
-    n, F0, hidden, classes, B = 6000, 20, 48, 6, 256
-    indptr, indices = l0.synth_graph(n, 18.0, seed=2)
-    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(7, 5, 3), max_batch=B, mode=abi.MODE_GRAPH)
-    eng.submit_seeds([np.random.default_rng(8).permutation(n)[:B]])
-    slices = sg.slices_of(eng)
-    feats = torch.randn(n, F0, device="cuda")
-    model = sg.DistSAGEModel(F0, hidden, classes, n_layers=3).cuda()
-    w = torch.randn(B, classes, device="cuda")
-    res = []
-    for layerwise in (False, True):
-        monkeypatch.setattr(sg, "_LAYERWISE_LOCAL", layerwise)
-        model.zero_grad()
-        out = model.forward_local(slices, feats)
-        (out * w).sum().backward()
-        res.append((out.detach().clone(), [p.grad.clone() for p in model.parameters()]))
-    torch.testing.assert_close(res[0][0], res[1][0], rtol=0, atol=0)      # same forward kernels
-    for a_, b_ in zip(res[0][1], res[1][1]):
-        torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-5)
-    eng.close()
