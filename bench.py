@@ -188,7 +188,7 @@ def compat_leg(indptr, indices, args, B, samples=384, workers=32):
     ids = sum(len(s.layers[l][g].in_nodes) for l in range(3) for g in range(4))
     del s, csl
     return {"samples_per_sec": (n - 1) / dt, "samples": n - 1, "workers": workers,
-            "config": "native pybind module `cslicer`, fanout 10/10/10, 4 parts (v % 4), minibatch %d, host `long` "
+            "config": "native pybind module `cslicer`, fanout 10/10/10, 4 parts (v %% 4), minibatch %d, host `long` "
                       "lists per sample (PCIe + deep copy inclusive)" % B,
             "in_nodes_of_last_sample": ids, "constructor_seconds": t_load}
 
