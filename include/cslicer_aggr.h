@@ -47,6 +47,11 @@ int csl_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, int64
 int csl_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t n, const float* src, int64_t lds,
                              int32_t H, void* stream);
 
+/* the same where idx MAY repeat (push_from_remotes for all peers in one launch: several parts send a partial sum
+ * for the same owned node): fp32 atomics, the order of the additions is not deterministic */
+int csl_scatter_add_rows_atomic_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t n, const float* src, int64_t lds,
+                                    int32_t H, void* stream);
+
 /* x[k, :] /= max(deg[k], 1) */
 int csl_div_rows_f32(float* x, int64_t ldx, const int32_t* deg, int64_t n, int32_t H, void* stream);
 

@@ -14,7 +14,8 @@ from . import _abi
 SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_scatter_add_rows_f32", "csl_div_rows_f32", "csl_gat_fwd_f32", "csl_gat_bwd_f32",
            "csl_sage_cat_f32", "csl_sage_cat_bwd_f32", "csl_relu_bwd_colsum_f32", "csl_softmax_ce_f32",
-           "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch", "csl_adam_f32"]
+           "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch", "csl_adam_f32",
+           "csl_scatter_add_rows_atomic_f32"]
 _ready = False
 
 
@@ -28,6 +29,7 @@ def _lib():
         L.csl_gather_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_scatter_add_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_div_rows_f32.argtypes = [vp, i64, vp, i64, i32, vp]
+        L.csl_scatter_add_rows_atomic_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         f32 = C.c_float
         L.csl_gat_fwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
         L.csl_gat_bwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
@@ -129,6 +131,17 @@ def scatter_add_rows_(dst, idx, src):
         raise ValueError("dst must be row-contiguous")
     _chk(_lib().csl_scatter_add_rows_f32(_p(dst), dst.stride(0), _p(idx), idx.numel(), _p(src), src.stride(0),
                                          src.shape[1], _stream()), "csl_scatter_add_rows_f32")
+    return dst
+
+
+def scatter_add_rows_atomic_(dst, idx, src):
+    """dst[idx[k]] += src[k] in place where idx may repeat (all peers' partial sums in one launch; fp32 atomics)."""
+    src = _f32(src)
+    idx = _i32(idx)
+    if dst.stride(-1) != 1:
+        raise ValueError("dst must be row-contiguous")
+    _chk(_lib().csl_scatter_add_rows_atomic_f32(_p(dst), dst.stride(0), _p(idx), idx.numel(), _p(src), src.stride(0),
+                                                src.shape[1], _stream()), "csl_scatter_add_rows_atomic_f32")
     return dst
 
 

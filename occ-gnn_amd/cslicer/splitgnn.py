@@ -49,7 +49,7 @@ class Slice(object):
     """One BiPartite of graph mode on the device: int32 tensors that alias the engine's arena."""
 
     __slots__ = ("part", "n_parts", "in_nodes", "out_nodes", "indptr", "indices", "owned_out_nodes",
-                 "self_ids_in", "owned_degree", "from_ids", "to_ids", "n_in", "n_out", "n_owned")
+                 "self_ids_in", "owned_degree", "from_ids", "to_ids", "from_all", "to_all", "n_in", "n_out", "n_owned")
 
 
 def _arena_tensors(eng, device):
@@ -106,6 +106,8 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
                           for p in range(P)]
             s.to_ids = [seg(_abi.TO_IDS, g, t0 + int(lm.pair_off[1][g][p]), t0 + int(lm.pair_off[1][g][p + 1]))
                         for p in range(P)]
+            # the per-peer lists are contiguous (receiver / sender order, the own one empty): all peers at once
+            s.from_all, s.to_all = seg(_abi.FROM_IDS, g), seg(_abi.TO_IDS, g)
             s.n_in, s.n_out, s.n_owned = s.in_nodes.numel(), s.out_nodes.numel(), s.owned_out_nodes.numel()
             row[g] = s
         out.append(row)
@@ -325,21 +327,15 @@ class DistSAGEModel(nn.Module):
     def forward_rank(self, slices, feat, rank, comm, overlap=False):
         """One part per process: boundary partials go through `comm.all_to_all` (RCCL).
         overlap=True runs each layer's exchange on a side stream while the rows that stay on
-        this GPU are aggregated (`_OverlappedAggregate`); same numbers, different schedule."""
+        this GPU are aggregated (`_RankAggregate`); same numbers, different schedule."""
         L = len(slices)
         x = feat
         for k, conv in enumerate(self.convs):
             sl = slices[L - 1 - k][rank]
-            if overlap:
-                x = conv.finish_fused(sl, _OverlappedAggregate.apply(x, sl, comm), x, k + 1 < len(self.convs))
-                continue
-            agg = conv.local(sl, x)
-            send = conv.boundary(sl, agg)
-            recv, tie = comm.all_to_all(send, [sl.to_ids[p].numel() for p in range(sl.n_parts)], agg.shape[1])
-            # `tie` is a zero that depends on the exchange: every rank then runs the reverse
-            # exchange in backward even when it received (or sent) nothing in this layer
-            agg = conv.merge(sl, agg + tie, recv)
-            x = conv.finish_fused(sl, agg, x, k + 1 < len(self.convs))
+            # aggregation + boundary exchange + merge of a layer are ONE autograd node (`_RankAggregate`): 5 launches
+            # forward whatever the number of peers (the op chain local / boundary / merge of forward_parts is
+            # 2 + 2 (P - 1) launches and as many autograd nodes)
+            x = conv.finish_fused(sl, _RankAggregate.apply(x, sl, comm, bool(overlap)), x, k + 1 < len(self.convs))
         return x
 
 
@@ -500,74 +496,67 @@ class DistGATModel(nn.Module):
         return x
 
 
-class _OverlappedAggregate(torch.autograd.Function):
-    """local sum-aggregate + boundary exchange + merge of ONE layer on ONE rank, with the
-    all-to-all on the communicator's side stream while the rows that never leave the GPU are
-    still being aggregated.
+class _RankAggregate(torch.autograd.Function):
+    """local sum-aggregate + boundary exchange + merge of ONE layer on ONE rank (dist_sageconv.py:52-65:
+    pull_for_remotes, the exchange, push_from_remotes), as one autograd node.  The boundary lists of a slice are
+    contiguous over the peers, so one gather builds the send buffer and one (atomic) scatter-add merges what every
+    peer sent.  overlap=True puts the all-to-all on the communicator's side stream while the rows that never
+    leave the GPU are still being aggregated; same numbers, different schedule.
 
-    forward   rows owned by peers first -> send buffers -> [side stream: all-to-all]
+    forward   rows owned by peers first -> send buffer -> [all-to-all, side stream if overlap]
               || rows owned by this part -> wait -> add received partials into the owned rows
-    backward  grads of received partials -> [side stream: reverse all-to-all]
+    backward  grads of received partials -> [reverse all-to-all, side stream if overlap]
               || backward of the owned rows -> wait -> backward of the peer-owned rows
     """
 
     @staticmethod
-    def forward(ctx, x, sl, comm):
-        g, P = sl.part, sl.n_parts
-        peers = [p for p in range(P) if p != g]
-        remote_rows = torch.cat([sl.from_ids[p] for p in peers]) if peers else sl.from_ids[g]
-        send_counts = [0 if p == g else sl.from_ids[p].numel() for p in range(P)]
-        recv_counts = [0 if p == g else sl.to_ids[p].numel() for p in range(P)]
-        H = x.shape[1]
-        main = torch.cuda.current_stream()
-        side = comm.side_stream()
-        agg = torch.empty((sl.n_out, H), dtype=torch.float32, device=x.device)
-        aggr.spmm_sum(sl.indptr, sl.indices, x, sl.n_out, rows=remote_rows, out=agg)
-        send_cat = aggr.gather_rows(agg, remote_rows)
+    def _exchange(comm, buf, send_counts, recv_counts, overlap):
+        """all-to-all of row blocks; returns (received rows, event to wait for or None)."""
+        if not overlap:
+            return comm._exchange(buf, send_counts, recv_counts), None
+        main, side = torch.cuda.current_stream(), comm.side_stream()
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            recv_cat = comm._exchange(send_cat, send_counts, recv_counts)
+            out = comm._exchange(buf, send_counts, recv_counts)
             done = torch.cuda.Event()
             done.record(side)
-        send_cat.record_stream(side)
+        buf.record_stream(side)
+        return out, done
+
+    @staticmethod
+    def forward(ctx, x, sl, comm, overlap):
+        g, P = sl.part, sl.n_parts
+        send_counts = [0 if p == g else sl.from_ids[p].numel() for p in range(P)]
+        recv_counts = [0 if p == g else sl.to_ids[p].numel() for p in range(P)]
+        H = x.shape[1]
+        agg = torch.empty((sl.n_out, H), dtype=torch.float32, device=x.device)
+        aggr.spmm_sum(sl.indptr, sl.indices, x, sl.n_out, rows=sl.from_all, out=agg)
+        send_cat = aggr.gather_rows(agg, sl.from_all)
+        recv_cat, done = _RankAggregate._exchange(comm, send_cat, send_counts, recv_counts, overlap)
         aggr.spmm_sum(sl.indptr, sl.indices, x, sl.n_out, rows=sl.owned_out_nodes, out=agg)   # overlaps
-        main.wait_event(done)
-        recv_cat.record_stream(main)
-        o = 0
-        for p in range(P):                 # one peer at a time: rows repeat across peers, never inside one
-            c = recv_counts[p]
-            if c:
-                aggr.scatter_add_rows_(agg, sl.to_ids[p], recv_cat[o:o + c])
-            o += c
-        ctx.sl, ctx.comm, ctx.n_src = sl, comm, x.shape[0]
-        ctx.remote_rows, ctx.send_counts, ctx.recv_counts = remote_rows, send_counts, recv_counts
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+            recv_cat.record_stream(torch.cuda.current_stream())
+        aggr.scatter_add_rows_atomic_(agg, sl.to_all, recv_cat)   # an owned node may receive from several peers
+        ctx.sl, ctx.comm, ctx.n_src, ctx.overlap = sl, comm, x.shape[0], overlap
+        ctx.send_counts, ctx.recv_counts = send_counts, recv_counts
         return agg
 
     @staticmethod
     def backward(ctx, G):
         sl, comm = ctx.sl, ctx.comm
         G = G.contiguous()
-        P = sl.n_parts
-        to_cat = torch.cat([sl.to_ids[p] for p in range(P) if p != sl.part]) if P > 1 else sl.to_ids[0]
-        main = torch.cuda.current_stream()
-        side = comm.side_stream()
-        g_recv = aggr.gather_rows(G, to_cat)          # d loss / d (partials received from each peer)
-        ready = torch.cuda.Event()
-        ready.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(ready)
-            back = comm._exchange(g_recv, ctx.recv_counts, ctx.send_counts)   # grads of what this rank sent
-            done = torch.cuda.Event()
-            done.record(side)
-        g_recv.record_stream(side)
+        g_recv = aggr.gather_rows(G, sl.to_all)          # d loss / d (partials received from each peer)
+        back, done = _RankAggregate._exchange(comm, g_recv, ctx.recv_counts, ctx.send_counts, ctx.overlap)
         gx = aggr.spmm_sum_bwd(sl.indptr, sl.indices, G, ctx.n_src, rows=sl.owned_out_nodes)   # overlaps
-        main.wait_event(done)
-        back.record_stream(main)
-        g_remote = aggr.gather_rows(G, ctx.remote_rows) + back
-        aggr.spmm_sum_bwd(sl.indptr, sl.indices, g_remote, ctx.n_src, rows=ctx.remote_rows, compact=True, out=gx)
-        return gx, None, None
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+            back.record_stream(torch.cuda.current_stream())
+        g_remote = aggr.gather_rows(G, sl.from_all) + back   # grads of what this rank sent
+        aggr.spmm_sum_bwd(sl.indptr, sl.indices, g_remote, ctx.n_src, rows=sl.from_all, compact=True, out=gx)
+        return gx, None, None, None
 
 
 class _AllToAllRows(torch.autograd.Function):

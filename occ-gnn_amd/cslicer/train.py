@@ -134,10 +134,14 @@ class Trainer(object):
                     logits = self.model.forward_rank(slices, x, self.rank, self.comm, overlap=self.overlap)
             else:
                 logits = self.model.forward_parts(slices, {0: x})[0]
-            seeds = top.out_nodes[top.owned_out_nodes.long()].long()  # the seeds this rank owns, frontier order
-            y = self.labels[seeds if self.P == 1 else self.local_row[seeds].long()]
+            seeds = top.out_nodes[top.owned_out_nodes.long()]  # the seeds this rank owns, frontier order
             # mean over the WHOLE minibatch: sum of local losses / global seed count
-            loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / max(n_seeds, 1)
+            if self.kind == "sage" and logits.shape[0] > 0:
+                loss = aggr.SoftmaxCE.apply(logits, seeds, self.labels, 1.0 / max(n_seeds, 1), self.local_row)
+            else:
+                seeds = seeds.long()
+                y = self.labels[seeds if self.P == 1 else self.local_row[seeds].long()]
+                loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / max(n_seeds, 1)
             _roctx.pop()
         self.t_forward += time.perf_counter() - t1
         _roctx.push("backward")

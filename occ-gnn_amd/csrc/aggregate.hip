@@ -156,6 +156,19 @@ __global__ __launch_bounds__(BLK) void k_scatter_add_rows(float* __restrict__ ds
   }
 }
 
+// dst[idx[k], :] += src[k, :] where idx MAY repeat (the partial sums several peers send for the same owned node,
+// merged in one launch): fp32 atomics, one wave per row, 64 consecutive floats per instruction
+__global__ __launch_bounds__(BLK) void k_scatter_add_rows_atomic(float* __restrict__ dst, long long ldd,
+                                                                 const int* __restrict__ idx, long long n,
+                                                                 const float* __restrict__ src, long long lds, int H) {
+  const int lane = threadIdx.x & 63;
+  const long long k = (long long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+  if (k >= n) return;
+  const long long d = idx[k];
+  if (d < 0) return;
+  for (int c = lane; c < H; c += 64) atomicAdd(dst + d * ldd + c, src[k * lds + c]);
+}
+
 template <int G>
 __global__ __launch_bounds__(BLK) void k_div_rows(float* __restrict__ x, long long ldx,
                                                   const int* __restrict__ deg, long long n, int H, int vec_ok) {
@@ -632,6 +645,15 @@ int csl_scatter_add_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_
   const int G = group_for(H), v = vec_ok(src, lds, dst, ldd, H);
   DISPATCH_G(G, k_scatter_add_rows, n, dst, (long long)ldd, idx, (long long)n, src, (long long)lds,
              (int)H, v);
+  return done();
+}
+
+int csl_scatter_add_rows_atomic_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t n, const float* src, int64_t lds,
+                                    int32_t H, void* stream) {
+  if (n == 0) return CSL_OK;
+  if (n < 0 || H < 1 || !idx || !dst || !src) return CSL_E_INVALID;
+  hipLaunchKernelGGL(k_scatter_add_rows_atomic, dim3((unsigned)((n + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0,
+                     (hipStream_t)stream, dst, (long long)ldd, idx, (long long)n, src, (long long)lds, (int)H);
   return done();
 }
 

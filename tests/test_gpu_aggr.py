@@ -378,3 +378,16 @@ def test_adam_matches_torch(mods):
         ob.step()
     for a_, b_ in zip(pa, pb):
         torch.testing.assert_close(a_.detach(), b_.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_scatter_add_rows_atomic_with_repeated_rows(mods):
+    _, aggr, _ = mods
+    torch.manual_seed(9)
+    dst0 = torch.randn(300, 100, device="cuda")
+    idx = torch.randint(0, 300, (2000,), device="cuda").int()
+    idx[::17] = -1
+    src = torch.randn(2000, 100, device="cuda")
+    got = aggr.scatter_add_rows_atomic_(dst0.clone(), idx, src)
+    keep = idx >= 0
+    want = dst0.clone().index_add_(0, idx[keep].long(), src[keep])
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
