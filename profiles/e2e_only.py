@@ -26,6 +26,11 @@ ap.add_argument("--hidden", type=int, default=256)
 ap.add_argument("--heads", type=int, default=8)
 ap.add_argument("--fanout", default="15,10,5")
 ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--streams", type=int, default=8, help="minibatches the trainer's engine slices per round")
+ap.add_argument("--rank-path", action="store_true",
+                help="the one-process-per-part code path (RCCL collectives with a world of one) instead of the fused "
+                     "single-part one: what a rank of a multi-GPU job runs per step, minus the peers")
+ap.add_argument("--overlap", action="store_true")
 a = ap.parse_args()
 import torch  # noqa: E402
 
@@ -41,8 +46,15 @@ else:
 n = indptr.shape[0] - 1
 feats, labels = synthetic_node_data(n, 100, 47)
 fan = tuple(int(x) for x in a.fanout.split(","))
-t = Trainer(indptr, indices, feats, labels, 47, fanouts=fan, batch=a.batch, streams=8, hidden=a.hidden,
-            model=a.model, heads=a.heads)
+dist = None
+if a.rank_path:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+t = Trainer(indptr, indices, feats, labels, 47, fanouts=fan, batch=a.batch, streams=a.streams, hidden=a.hidden,
+            model=a.model, heads=a.heads, rank_path=a.rank_path, dist=dist, overlap=a.overlap)
 del feats
 t.set_nodes(np.random.default_rng(1).permutation(n))
 t.run(a.warmup)
@@ -54,5 +66,7 @@ torch.cuda.synchronize()
 _roctx.pop()
 dt = time.perf_counter() - t0
 print(json.dumps({"e2e_only": True, "model": a.model, "steps": a.steps, "ms_per_step": 1e3 * dt / a.steps,
-                  "iters_per_sec": a.steps / dt}))
+                  "iters_per_sec": a.steps / dt, "rank_path": a.rank_path, "overlap": a.overlap, "streams": a.streams}))
 t.close()
+if dist is not None:
+    dist.destroy_process_group()
