@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--e2e-hidden", type=int, default=256)
     ap.add_argument("--e2e-feat", type=int, default=100)
     ap.add_argument("--e2e-classes", type=int, default=47)
-    ap.add_argument("--e2e-streams", type=int, default=8, help="minibatches the trainer's engine slices per round")
+    ap.add_argument("--e2e-streams", type=int, default=32, help="minibatches the trainer's engine slices per round")
     ap.add_argument("--no-compat", action="store_true", help="skip the reference-surface (host lists) leg")
     ap.add_argument("--same-batch", action="store_true",
                     help="experiment (profiles/pmc_same_batch.sh): every stream slices the SAME minibatch, so all S "

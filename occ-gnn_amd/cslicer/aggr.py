@@ -359,8 +359,15 @@ class Adam(object):
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def step(self):
+    def step(self, flat_grads=None):
+        """flat_grads: optional contiguous fp32 tensor holding every parameter's gradient back to back (in
+        parameter order) -- the all-reduced buffer of a multi-rank job is used in place, not copied back."""
+        o = 0
         for k, p in enumerate(self.params):
+            if flat_grads is not None:
+                self._g[k] = flat_grads.data_ptr() + 4 * o
+                o += p.numel()
+                continue
             g = p.grad
             if g is None:
                 raise RuntimeError("parameter %d has no gradient" % k)

@@ -154,18 +154,14 @@ class Trainer(object):
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                               for p in self.model.parameters()])
             self.dist.all_reduce(flat)                    # replicated weights: sum of per-rank gradients
-            o = 0
-            for p in self.model.parameters():
-                n = p.numel()
-                if p.grad is None:
-                    p.grad = flat[o:o + n].view_as(p).clone()
-                else:
-                    p.grad.copy_(flat[o:o + n].view_as(p))
-                o += n
             _roctx.pop()
-        _roctx.push("optimizer")
-        self.opt.step()
-        _roctx.pop()
+            _roctx.push("optimizer")
+            self.opt.step(flat_grads=flat)                # the reduced buffer is used in place
+            _roctx.pop()
+        else:
+            _roctx.push("optimizer")
+            self.opt.step()
+            _roctx.pop()
         self.steps_done += 1
         return loss.detach()
 
