@@ -523,6 +523,7 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
   __shared__ unsigned long long s_ri[TN];
   __shared__ uint32_t s_rng[TN];
   __shared__ uint32_t s_hb[TN];
+  __shared__ uint8_t s_to[TN];  // owner part of the tile's nodes
   __shared__ uint32_t s_wn[NW];
   __shared__ uint32_t s_cnt[5 * CSL_MAX_PARTS];
   __shared__ uint32_t s_ec[TN * CSL_MAX_PARTS];                                 // graph: edges per (node, source part)
@@ -552,6 +553,7 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
     s_v[n] = v;
     s_ri[n] = ri;
     s_hb[n] = 0;
+    s_to[n] = i < F ? (uint8_t)owner(a, v) : 0;
     if (a.graph) {
       for (uint32_t k = n; k < TN * P; k += TN) s_ec[k] = 0;
       if (n < CSL_MAX_PARTS + CSL_MAX_PARTS * CSL_MAX_PARTS) s_gcnt[n] = 0;
@@ -635,8 +637,15 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
 #pragma unroll
       for (int u = 0; u < SU; u++) {
         if (live[u]) {
+          // The flag byte every candidate gets here is what k_bucket would find in the common case: a self entry
+          // new to the frontier, an edge candidate the first occurrence of its node (in the frontier and among its
+          // slice's in-nodes) and not a frontier node itself.  k_bucket then only stores the exceptions (a fifth of
+          // the entries) instead of one scattered byte per first occurrence (most entries): its evaluate phase was
+          // bound by exactly those stores.  bit0 new-frontier, bit1 first-in-node, bits 2-4 owner part.
+          uint32_t fl = 0;
           if (slu[u] == 0) {
             atomicAdd(&s_bh[bucket_of(val[u], nb)], 1u);
+            fl = (a.graph ? 3u : 1u) | ((uint32_t)s_to[nnu[u]] << 2);
           } else if (val[u] != UNSET) {
             if (val[u] == vvu[u]) {
               // a sampled self loop only re-adds the self edge (slicer.cpp:33-35,
@@ -648,10 +657,11 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
               atomicOr(&s_hb[nnu[u]], 1u << og);
               if (a.graph) atomicAdd(&s_ec[nnu[u] * P + og], 1u);
               atomicAdd(&s_bh[bucket_of(val[u], nb)], 1u);
+              fl = 3u | (og << 2);
             }
           }
           a.cand[cbase + k0 + u * TN] = val[u];
-          a.cflag[cbase + k0 + u * TN] = 0;  // k_bucket overwrites the flags of real candidates
+          a.cflag[cbase + k0 + u * TN] = (uint8_t)fl;  // k_bucket corrects the exceptions
           if (a.candk && (val[u] != UNSET || slu[u] == 0 || !gat[u])) a.candk[cbase + k0 + u * TN] = val[u];
         }
       }
@@ -662,7 +672,8 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
     const bool act = i < F;
     if (act) {
       hb = s_hb[n];
-      to = owner(a, v);
+      to = s_to[n];
+      if (!a.graph) a.firstpos[s * a.fcap + i] = UNSET;  // k_bucket stores it for nodes that are sampled as a neighbour too
       // graph mode: a node is always an out node of its own slice
       if (a.graph) hb |= 1u << to;
       a.hasedge[s * a.fcap + i] = hb;
@@ -854,7 +865,8 @@ __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
 // of its node (a) in the next frontier (out_dr mask, slicer.cpp:45-49) and
 // (b) among the in_nodes of its slice (order_and_remove_duplicates,
 // bipartite.cpp:4).  flag byte: bit0 new-frontier, bit1 first-in-node,
-// bits2-4 owner part, bit5 the node is also a frontier node of this layer.
+// bits2-4 owner part, bit5 the node is also a frontier node of this layer
+// (k_sample pre-writes the common-case flag; only exceptions are stored here).
 __device__ __forceinline__ uint32_t ht_find(const uint32_t* h_key, uint32_t val) {
   uint32_t h = slot_of(val);
   for (uint32_t probes = 0; probes < (uint32_t)HCAP; probes++) {
@@ -948,24 +960,29 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
         if (a.graph) atomicOr(&a.meta[s].error, (uint32_t)CSL_ERR_DUP_SEED);
         else a.dupflag[s] = 1u;
       }
-      // k_sample left every flag byte zero: only candidates that are a first occurrence are written
+      // k_sample gave every self entry the flag of the common case (new to the frontier; graph mode: also the
+      // first source occurrence): only the exceptions are stored here, as 0
       if (a.graph) {
         const uint32_t fe = epos == c;  // epos already includes the self entry
-        if (fe) cflag[c] = (uint8_t)(fe | (fe << 1) | (g << 2));
+        if (!fe) cflag[c] = 0;
+        a.firstpos[s * a.fcap + i] = epos;
       } else {
         // new to the frontier: no edge occurrence before it (UNSET compares greater than any position) and,
         // for a repeated seed id, the first of its self entries (slicer.cpp:45-49)
         const uint32_t newf = epos > c && self == i;
-        if (newf) cflag[c] = (uint8_t)(newf | (g << 2));
+        if (!newf) cflag[c] = 0;
         if (a.layer == 0) a.seedrep[s * a.fcap0 + i] = self;
+        if (epos != UNSET) a.firstpos[s * a.fcap + i] = epos;  // (k_sample left UNSET)
       }
-      a.firstpos[s * a.fcap + i] = epos;
     } else {
+      // edge candidates carry "first occurrence, not a frontier node" (3 | g << 2) from k_sample
       const uint32_t c = ee.y;
       const uint32_t fe = epos == c;
-      if (fe) {
-        const uint32_t newf = a.graph ? fe : (self == UNSET || (unsigned long long)self * W > c);
-        cflag[c] = (uint8_t)(newf | (fe << 1) | (g << 2) | (self != UNSET ? 32u : 0u));
+      if (!fe) {
+        cflag[c] = 0;
+      } else if (!a.graph && self != UNSET) {
+        const uint32_t newf = (unsigned long long)self * W > c;
+        cflag[c] = (uint8_t)(newf | 2u | (g << 2) | 32u);  // bit 5: k_emit keeps its in-node rank for k_selfin
       }
       if (a.graph) a.srcpos[(size_t)s * a.ccap + c] = epos;
     }
