@@ -658,6 +658,8 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
               if (a.graph) atomicAdd(&s_ec[nnu[u] * P + og], 1u);
               atomicAdd(&s_bh[bucket_of(val[u], nb)], 1u);
               fl = 3u | (og << 2);
+              // graph mode: an edge's source position is its own position unless k_bucket finds an earlier one
+              if (a.graph) a.srcpos[cbase + k0 + u * TN] = tile * TN * W + k0 + u * TN;
             }
           }
           a.cand[cbase + k0 + u * TN] = val[u];
@@ -984,7 +986,7 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
         const uint32_t newf = (unsigned long long)self * W > c;
         cflag[c] = (uint8_t)(newf | 2u | (g << 2) | 32u);  // bit 5: k_emit keeps its in-node rank for k_selfin
       }
-      if (a.graph) a.srcpos[(size_t)s * a.ccap + c] = epos;
+      if (a.graph && !fe) a.srcpos[(size_t)s * a.ccap + c] = epos;  // (k_sample stored c itself)
     }
   };
   auto evaluate = [&](const uint2 ee, const uint32_t h) { judge(ee, h_epos[h], h_self[h], part_of(ee.x)); };
