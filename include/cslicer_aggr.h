@@ -71,6 +71,17 @@ int csl_gat_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_row
                     const float* g_n, float* g_el, float* g_er, float* g_z, void* stream);
 
 
+/* GAT attention logits (DistGATConv.project): el[r, h] = <z[r, h, :], attn_l[h, :]>, er likewise; z [n, H*D],
+ * attn_* [H, D], el/er [n, H]; D % 4 == 0, D <= 256, 16-byte aligned.  Backward: g_z [n, H*D] is WRITTEN
+ * (g_el a_l + g_er a_r), g_attn_l / g_attn_r [H, D] are the sums over the rows (two-stage, no atomics);
+ * scratch: csl_gat_logits_bwd_scratch(n, H, D) floats. */
+int csl_gat_logits_fwd_f32(const float* z, const float* attn_l, const float* attn_r, int64_t n, int32_t H, int32_t D,
+                           float* el, float* er, void* stream);
+int64_t csl_gat_logits_bwd_scratch(int64_t n, int32_t H, int32_t D);
+int csl_gat_logits_bwd_f32(const float* z, const float* attn_l, const float* attn_r, const float* g_el,
+                           const float* g_er, int64_t n, int32_t H, int32_t D, float* g_z, float* g_attn_l,
+                           float* g_attn_r, float* scratch, void* stream);
+
 /* ---- fused GraphSAGE layer pieces (DistSageConv.forward, python/layers/dist_sageconv.py:42-84) ----
  *
  * csl_sage_cat_f32: the operand of Linear(2*in, out) in one pass (self_gather + gather/mean + concat,

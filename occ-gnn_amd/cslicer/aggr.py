@@ -15,7 +15,8 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_scatter_add_rows_f32", "csl_div_rows_f32", "csl_gat_fwd_f32", "csl_gat_bwd_f32",
            "csl_sage_cat_f32", "csl_sage_cat_bwd_f32", "csl_relu_bwd_colsum_f32", "csl_softmax_ce_f32",
            "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch", "csl_adam_f32",
-           "csl_scatter_add_rows_atomic_f32"]
+           "csl_scatter_add_rows_atomic_f32", "csl_gat_logits_fwd_f32", "csl_gat_logits_bwd_f32",
+           "csl_gat_logits_bwd_scratch"]
 _ready = False
 
 
@@ -30,6 +31,10 @@ def _lib():
         L.csl_scatter_add_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_div_rows_f32.argtypes = [vp, i64, vp, i64, i32, vp]
         L.csl_scatter_add_rows_atomic_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
+        L.csl_gat_logits_fwd_f32.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
+        L.csl_gat_logits_bwd_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, vp, vp, vp]
+        L.csl_gat_logits_bwd_scratch.argtypes = [i64, i32, i32]
+        L.csl_gat_logits_bwd_scratch.restype = i64
         f32 = C.c_float
         L.csl_gat_fwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp]
         L.csl_gat_bwd_f32.argtypes = [vp, vp, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
@@ -322,6 +327,40 @@ class GatAggregate(torch.autograd.Function):
         _chk(_lib().csl_gat_bwd_f32(_p(indptr), _p(indices), n_rows, _p(el), _p(er), _p(z), H, D, slope, _p(m),
                                     _p(gs), _p(gn), _p(g_el), _p(g_er), _p(g_z), _stream()), "csl_gat_bwd_f32")
         return g_el, g_er, g_z, None, None, None, None, None, None
+
+
+class GatLogits(torch.autograd.Function):
+    """(el, er) [n, H] = <z[:, h, :], attn_l[h, :]>, <z[:, h, :], attn_r[h, :]> for z [n, H*D]: one row-wise HIP pass
+    over z (csl_gat_logits_fwd_f32 / _bwd_f32) instead of two [n, in] x [in, H] library GEMMs with H = 8 columns."""
+
+    @staticmethod
+    def forward(ctx, z, attn_l, attn_r):
+        z, al, ar = _f32(z).contiguous(), _f32(attn_l).contiguous(), _f32(attn_r).contiguous()
+        H, D = al.shape
+        n = z.shape[0]
+        if z.shape[1] != H * D or ar.shape != al.shape:
+            raise ValueError("z [n, H*D], attn_l / attn_r [H, D] expected")
+        el = torch.empty((n, H), dtype=torch.float32, device=z.device)
+        er = torch.empty((n, H), dtype=torch.float32, device=z.device)
+        _chk(_lib().csl_gat_logits_fwd_f32(_p(z), _p(al), _p(ar), n, H, D, _p(el), _p(er), _stream()),
+             "csl_gat_logits_fwd_f32")
+        ctx.save_for_backward(z, al, ar)
+        return el, er
+
+    @staticmethod
+    def backward(ctx, g_el, g_er):
+        z, al, ar = ctx.saved_tensors
+        H, D = al.shape
+        n = z.shape[0]
+        g_el, g_er = _f32(g_el).contiguous(), _f32(g_er).contiguous()
+        g_z = torch.empty_like(z)
+        L = _lib()
+        buf = torch.empty((2 * H * D + max(int(L.csl_gat_logits_bwd_scratch(n, H, D)), 4),), dtype=torch.float32,
+                          device=z.device)
+        _chk(L.csl_gat_logits_bwd_f32(_p(z), _p(al), _p(ar), _p(g_el), _p(g_er), n, H, D, _p(g_z),
+                                      C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr() + 4 * H * D),
+                                      C.c_void_p(buf.data_ptr() + 8 * H * D), _stream()), "csl_gat_logits_bwd_f32")
+        return g_z, buf[:H * D].view(H, D), buf[H * D:2 * H * D].view(H, D)
 
 
 def attention_gather(indptr, indices, u_in, v_in, n_rows):

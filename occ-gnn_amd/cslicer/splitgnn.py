@@ -369,8 +369,9 @@ class DistGATConv(nn.Module):
         nn.init.xavier_normal_(self.attn_r, gain=gain)
 
     def project(self, x):
-        """z = W x and the two attention logits per head.  el = <z, a_l> = x (a_l W)^T: the logits are two
-        [rows, in] x [in, H] GEMMs on x instead of elementwise products and reductions over the wide z."""
+        """z = W x and the two attention logits per head, el = <z, a_l>, er = <z, a_r>: one GEMM and one row-wise
+        HIP reduction over z (`aggr.GatLogits`; as two [rows, in] x [in, H] GEMMs on x the logits were the slowest
+        kernels of the step: H = 8 output columns)."""
         w = self.fc.weight
         m = x.shape[0]
         if m >= ROW_PAD:  # tall operand: shapes that repeat + slab-wise weight gradient (see _SplitKLinear)
@@ -379,16 +380,21 @@ class DistGATConv(nn.Module):
             z = _SplitKLinear.apply(xp, w, None)[:m]
         else:
             z = self.fc(x)
-        w3 = w.view(self.H, self.D, -1)
-        wl = (self.attn_l.unsqueeze(-1) * w3).sum(1)  # [H, in]
-        wr = (self.attn_r.unsqueeze(-1) * w3).sum(1)
-        return z, x @ wl.t(), x @ wr.t()
+        el, er = aggr.GatLogits.apply(z, self.attn_l, self.attn_r)
+        return z, el, er
 
     def forward_parts(self, sl, x):
         """sl[g]: Slice of part g, x[g]: features of sl[g].in_nodes.  Returns per part the [n_owned, H*D]
         output rows of the nodes it owns (frontier order)."""
         parts = sorted(sl.keys())
         H, D = self.H, self.D
+        if len(parts) == 1 and sl[parts[0]].n_parts == 1:
+            # one part holding every node: every out node is owned (owned_out_nodes = 0..n_out-1), nothing to merge
+            g = parts[0]
+            z, el, er = self.project(x[g])
+            er_out = aggr.GatherRows.apply(er, sl[g].self_ids_in)
+            _, S, N = aggr.GatAggregate.apply(el, er_out, z, sl[g].indptr, sl[g].indices, sl[g].n_out, H, D, self.slope)
+            return {g: (N.view(-1, H, D) / S.clamp_min(1e-30).unsqueeze(-1)).reshape(-1, H * D) + self.bias}
         proj = {g: self.project(x[g]) for g in parts}
         # er of the destinations: owned rows from the part's own projection ...
         er_out = {}

@@ -577,6 +577,83 @@ __global__ __launch_bounds__(BLK) void k_adam(AdamArgs a, float b1, float b2, fl
   }
 }
 
+// ---- GAT attention logits: el[r, h] = <z[r, h, :], a_l[h, :]>, er likewise (DistGATConv.project).  A row-wise
+// reduction over z (one HBM pass, 1 KB per row at 8 heads x 32); as `[rows, in] x [in, H]` library GEMMs the same
+// numbers took 0.2-0.8 ms per launch (H = 8 columns: MT32x16x512 tiles), 1.7 ms of the 5.9 ms GAT step.
+// One wave per row, a lane owns 4 consecutive columns (D % 4 == 0), heads are groups of D / 4 lanes.
+__global__ __launch_bounds__(BLK) void k_gat_logits_fwd(const float* __restrict__ z, const float* __restrict__ al,
+                                                        const float* __restrict__ ar, long long n, int H, int D,
+                                                        float* __restrict__ el, float* __restrict__ er) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int C = H * D, gsz = D / 4, lpc = (64 / gsz) * gsz, gl = lane % gsz;
+  for (int c0 = 0; c0 < C; c0 += lpc * 4) {
+    const int c = c0 + lane * 4;
+    const bool on = lane < lpc && c < C;
+    float dl = 0.f, dr = 0.f;
+    if (on) {
+      const float4 zv = *reinterpret_cast<const float4*>(z + r * C + c);
+      const float4 a = *reinterpret_cast<const float4*>(al + c), b = *reinterpret_cast<const float4*>(ar + c);
+      dl = zv.x * a.x + zv.y * a.y + zv.z * a.z + zv.w * a.w;
+      dr = zv.x * b.x + zv.y * b.y + zv.z * b.z + zv.w * b.w;
+    }
+    for (int o = 1; o < gsz; o <<= 1) {  // segmented tree over the head's lane group
+      const float tl = __shfl_down(dl, o), tr = __shfl_down(dr, o);
+      if (gl + o < gsz) dl += tl, dr += tr;
+    }
+    if (on && gl == 0) {
+      el[r * H + c / D] = dl;
+      er[r * H + c / D] = dr;
+    }
+  }
+}
+// backward: g_z[r, h, :] = g_el[r, h] a_l[h, :] + g_er[r, h] a_r[h, :]; per-block partial sums of
+// g_a_l[h, :] = sum_r g_el[r, h] z[r, h, :] (and g_a_r) for k_colsum_finish
+__global__ __launch_bounds__(BLK) void k_gat_logits_bwd(const float* __restrict__ z, const float* __restrict__ al,
+                                                        const float* __restrict__ ar, const float* __restrict__ g_el,
+                                                        const float* __restrict__ g_er, long long n, int H, int D,
+                                                        float* __restrict__ g_z, float* __restrict__ part_l,
+                                                        float* __restrict__ part_r, long long rows_per_block) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int C = H * D, gsz = D / 4, lpc = (64 / gsz) * gsz;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r_end = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  __shared__ float s_l[BLK * 4], s_r[BLK * 4];
+  for (int c0 = 0; c0 < C; c0 += lpc * 4) {  // block-uniform
+    const int c = c0 + lane * 4;
+    const bool on = lane < lpc && c < C;
+    const int h = on ? c / D : 0;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, pl = a, pr = a;
+    if (on) {
+      a = *reinterpret_cast<const float4*>(al + c);
+      b = *reinterpret_cast<const float4*>(ar + c);
+    }
+    for (long long r = r0 + w; r < r_end; r += BLK / 64) {
+      if (!on) continue;
+      const float gl_ = g_el[r * H + h], gr_ = g_er[r * H + h];
+      const float4 zv = *reinterpret_cast<const float4*>(z + r * C + c);
+      float4 o;
+      o.x = gl_ * a.x + gr_ * b.x, o.y = gl_ * a.y + gr_ * b.y, o.z = gl_ * a.z + gr_ * b.z, o.w = gl_ * a.w + gr_ * b.w;
+      *reinterpret_cast<float4*>(g_z + r * C + c) = o;
+      pl.x += gl_ * zv.x, pl.y += gl_ * zv.y, pl.z += gl_ * zv.z, pl.w += gl_ * zv.w;
+      pr.x += gr_ * zv.x, pr.y += gr_ * zv.y, pr.z += gr_ * zv.z, pr.w += gr_ * zv.w;
+    }
+    __syncthreads();
+    reinterpret_cast<float4*>(s_l)[threadIdx.x] = pl;
+    reinterpret_cast<float4*>(s_r)[threadIdx.x] = pr;
+    __syncthreads();
+    if (w == 0 && on) {
+      for (int k = 1; k < BLK / 64; k++) {
+        add4(pl, reinterpret_cast<float4*>(s_l)[k * 64 + lane]);
+        add4(pr, reinterpret_cast<float4*>(s_r)[k * 64 + lane]);
+      }
+      *reinterpret_cast<float4*>(part_l + (long long)blockIdx.x * C + c) = pl;
+      *reinterpret_cast<float4*>(part_r + (long long)blockIdx.x * C + c) = pr;
+    }
+  }
+}
+
 int group_for(int H) {
   int q = (H + 3) / 4, g = 1;
   while (g < q && g < 64) g <<= 1;
@@ -800,6 +877,41 @@ int csl_adam_f32(int32_t count, float* const* params, const float* const* grads,
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(BLK), 0, (hipStream_t)stream, a, beta1, beta2,
                      (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), eps);
+  return done();
+}
+
+int csl_gat_logits_fwd_f32(const float* z, const float* attn_l, const float* attn_r, int64_t n, int32_t H, int32_t D,
+                           float* el, float* er, void* stream) {
+  if (n == 0) return CSL_OK;
+  if (n < 0 || !el || !er || !gat_args_ok(z, attn_l, attn_r, H, D)) return CSL_E_INVALID;
+  hipLaunchKernelGGL(k_gat_logits_fwd, dim3((unsigned)((n + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, (hipStream_t)stream,
+                     z, attn_l, attn_r, (long long)n, (int)H, (int)D, el, er);
+  return done();
+}
+
+int64_t csl_gat_logits_bwd_scratch(int64_t n, int32_t H, int32_t D) {
+  const long long rpb = rb_rows(n);
+  return 2 * ((n + rpb - 1) / rpb) * (int64_t)H * D;
+}
+
+int csl_gat_logits_bwd_f32(const float* z, const float* attn_l, const float* attn_r, const float* g_el,
+                           const float* g_er, int64_t n, int32_t H, int32_t D, float* g_z, float* g_attn_l,
+                           float* g_attn_r, float* scratch, void* stream) {
+  if (n < 0 || !g_attn_l || !g_attn_r || H < 1 || D < 4 || D % 4 != 0 || D > 256) return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = H * D;
+  const long long rpb = rb_rows(n);
+  const long long blocks = (n + rpb - 1) / rpb;
+  if (blocks > 0) {
+    if (!g_el || !g_er || !g_z || !scratch || !gat_args_ok(z, attn_l, attn_r, H, D) || !aligned16(g_z) ||
+        !aligned16(scratch))
+      return CSL_E_INVALID;
+    hipLaunchKernelGGL(k_gat_logits_bwd, dim3((unsigned)blocks), dim3(BLK), 0, st, z, attn_l, attn_r, g_el, g_er,
+                       (long long)n, (int)H, (int)D, g_z, scratch, scratch + blocks * C, rpb);
+  }
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, C, g_attn_l);
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch + blocks * C, blocks, C,
+                     g_attn_r);
   return done();
 }
 

@@ -212,3 +212,25 @@ def test_gat_config5_shape_eight_parts(mods):
         want = fin.grad[ids].float()
         torch.testing.assert_close(x[g].grad, want, rtol=2e-3, atol=1e-3 * max(float(want.abs().max()), 1e-3))
     eng.close()
+
+
+@pytest.mark.parametrize("H,D,n", [(8, 32, 5000), (4, 12, 333), (1, 4, 70), (2, 256, 900), (3, 48, 1)])
+def test_gat_logits_kernel_matches_torch(mods, H, D, n):
+    """aggr.GatLogits (csl_gat_logits_fwd_f32 / _bwd_f32) against (z.view(n, H, D) * a).sum(-1) in torch."""
+    _, aggr, _ = mods
+    torch.manual_seed(H * D + n)
+    z0 = torch.randn(n, H * D, device="cuda")
+    al0, ar0 = torch.randn(H, D, device="cuda"), torch.randn(H, D, device="cuda")
+    gl, gr = torch.randn(n, H, device="cuda"), torch.randn(n, H, device="cuda")
+    res = []
+    for which in ("hip", "torch"):
+        z, al, ar = (t.clone().requires_grad_() for t in (z0, al0, ar0))
+        if which == "hip":
+            el, er = aggr.GatLogits.apply(z, al, ar)
+        else:
+            zv = z.view(n, H, D)
+            el, er = (zv * al).sum(-1), (zv * ar).sum(-1)
+        ((el * gl).sum() + (er * gr).sum()).backward()
+        res.append((el.detach(), er.detach(), z.grad, al.grad, ar.grad))
+    for name, a_, b_ in zip(["el", "er", "grad z", "grad a_l", "grad a_r"], res[0], res[1]):
+        torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-4 * max(1.0, float(b_.abs().max())), msg=lambda m_: name + ": " + m_)

@@ -177,6 +177,24 @@ def test_train_cli_prints_reference_keys(capsys, model):
         assert key in out
 
 
+def test_train_cli_on_an_l0_directory_with_partition_file(capsys, tmp_path):
+    """`python -m cslicer.train --graph <L0 dir> --partition file`: features/labels are read memory-mapped (own rows
+    only), ownership comes from partition_map_opt.bin (all zeros here: one rank), the epoch's tail minibatch is
+    trained once (7 minibatches of 300 over 2000 nodes: 6 full + one of 200)."""
+    from cslicer import l0, train
+    n = 2000
+    indptr, indices = l0.synth_graph(n, 9.0, seed=4)
+    rng = np.random.default_rng(0)
+    feats = rng.random((n, 12), dtype=np.float32)
+    labels = rng.integers(0, 3, size=n).astype(np.int32)
+    d = str(tmp_path / "tiny")
+    l0.write_l0(d, indptr, indices, features=feats, labels=labels, partition=np.zeros(n, dtype=np.int32), num_classes=3)
+    train.main(["--graph", d, "--partition", "file", "--fan-out", "4,6", "--num-layers", "2", "--num-hidden", "16",
+                "--batch-size", "300", "--num-epochs", "1"])
+    out = capsys.readouterr().out
+    assert "epoch 0: 7 minibatches" in out and "avg forward time" in out
+
+
 def _nccl_single_rank(port, q, kind):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
