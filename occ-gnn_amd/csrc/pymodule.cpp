@@ -456,7 +456,13 @@ class CSlicer {
     conv.join();
   }
 
-  MiniPool pool_{3};
+  // helpers of the converter thread (int32 -> long widening of a sample's 12 BiPartites); CSLICER_CONVERT_THREADS
+  static int convert_helpers() {
+    const char* e = getenv("CSLICER_CONVERT_THREADS");
+    const int n = e ? atoi(e) : 3;
+    return n < 0 ? 0 : (n > 15 ? 15 : n);
+  }
+  MiniPool pool_{convert_helpers()};
   std::mutex cv_m_;
   std::condition_variable cv_;
   Staged staged_;
