@@ -124,7 +124,9 @@ def test_empty_round_and_empty_streams(abi):
 
 
 # CSLICER_FUZZ_SEEDS=N / CSLICER_FUZZ_SCALE=K widen the campaign (one-off runs after the kernel rewrites of
-# round 1: 400 seeds at scale 1 and 60 seeds at scale 25 (graphs up to 150 k nodes, batches up to 7500), all clean)
+# round 1: 400 seeds at scale 1 and 60 seeds at scale 25 (graphs up to 150 k nodes, batches up to 7500), all clean;
+# after round 2's -- last-block scans, pre-written flags, repeated seed ids, edge stream compared too -- 300 seeds at
+# scale 1 and 50 at scale 25, all clean)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CSLICER_FUZZ_SEEDS", "12"))))
 def test_randomised_configurations(abi, orc, seed):
     """Random graph shape, fanouts (incl. 1 and > 16), parts, batch, streams, workload table."""
@@ -142,6 +144,9 @@ def test_randomised_configurations(abi, orc, seed):
     wl = rng.integers(0, P, size=n).astype(np.int32) if rng.random() < 0.5 else None
     perm = rng.permutation(n)
     mode_graph = bool(rng.random() < 0.4)
+    if not mode_graph and rng.random() < 0.35:
+        # strict mode takes minibatches with repeated seed ids (bipartite.cpp:3-17): the node order itself repeats
+        perm = rng.integers(0, n, size=n)
     e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2, workload=wl,
                    mode=abi.MODE_GRAPH if mode_graph else abi.MODE_STRICT, flags=abi.FLAG_KEEP_CANDIDATES)
     e.set_nodes(perm)
