@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--e2e-feat", type=int, default=100)
     ap.add_argument("--e2e-classes", type=int, default=47)
     ap.add_argument("--e2e-streams", type=int, default=32, help="minibatches the trainer's engine slices per round")
+    ap.add_argument("--no-tuned-gemms", action="store_true",
+                    help="e2e leg: hipBLASLt's default heuristic instead of the recorded TunableOp selections")
     ap.add_argument("--no-compat", action="store_true", help="skip the reference-surface (host lists) leg")
     ap.add_argument("--same-batch", action="store_true",
                     help="experiment (profiles/pmc_same_batch.sh): every stream slices the SAME minibatch, so all S "
@@ -496,7 +498,8 @@ def main():
 
     # ---- end-to-end minibatch rate: slice + feature gather + forward/backward + Adam, one part per GPU
     def e2e_leg():
-        from cslicer.train import Trainer, synthetic_node_data
+        from cslicer.train import Trainer, synthetic_node_data, use_tuned_gemms
+        tuned = (not args.no_tuned_gemms) and use_tuned_gemms()
         # every rank generates only the feature/label rows of the nodes it owns (counter-based generator)
         feats = lambda own: synthetic_node_data(N, args.e2e_feat, args.e2e_classes, seed=0, rows=own)[0]  # noqa: E731
         labels = lambda own: synthetic_node_data(N, 1, args.e2e_classes, seed=0, rows=own)[1]            # noqa: E731
@@ -532,6 +535,7 @@ def main():
             }
         return {
             "roofline": roof,
+            "tuned_gemm_selections": bool(tuned),
             "iters_per_sec": args.e2e_steps / t_e2e, "ms_per_iter": 1e3 * t_e2e / args.e2e_steps,
             "steps": args.e2e_steps,
             "config": "split-parallel %s fanout %s, batch %d (global), %d part(s) = %d GPU(s), features %d, "

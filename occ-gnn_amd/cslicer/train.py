@@ -13,6 +13,7 @@ The print keys of train.py:101-103 are kept (`avg forward time`, `batch slice ti
 `cache refresh time`; there is no feature cache here: features are resident in HBM, so the last
 one is reported as 0).
 """
+import os
 import time
 
 import numpy as np
@@ -220,6 +221,22 @@ class Trainer(object):
 
     def close(self):
         self.eng.close()
+
+
+TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+
+
+def use_tuned_gemms(path=TUNED_GEMMS):
+    """Let torch pick the library GEMM kernels recorded in `path` (PyTorch TunableOp results for the trainer's
+    shapes on gfx950, written by profiles/tune_gemms.sh) instead of hipBLASLt's default heuristic: the deepest
+    layer's forward GEMM runs in 81 us instead of 100, its weight gradient in 73 instead of 83.  Recorded
+    selections only, no tuning at run time; shapes that are not in the file keep the default.  Process-wide."""
+    if not os.path.exists(path) or not hasattr(torch.cuda, "tunable"):
+        return False
+    torch.cuda.tunable.enable(True)
+    torch.cuda.tunable.tuning_enable(False)
+    torch.cuda.tunable.set_filename(path)
+    return True
 
 
 def _mix64(x):

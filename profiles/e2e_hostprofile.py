@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Host-side profile (cProfile) of the end-to-end training step: where a 1.7 ms step spends its
-Python/launch time.  usage: python3 profiles/e2e_hostprofile.py [steps]"""
+"""Host-side profile (cProfile) of the end-to-end training step: where a step spends its Python/launch time.
+usage: python3 profiles/e2e_hostprofile.py [steps] [rank]   (rank: the one-process-per-part path, RCCL world of one)"""
 import cProfile
 import os
 import pstats
@@ -21,7 +21,16 @@ else:
     indptr, indices = l0.synth_graph(2_449_029, 50.5, seed=0)
 n = indptr.shape[0] - 1
 feats, labels = synthetic_node_data(n, 100, 47)
-t = Trainer(indptr, indices, feats, labels, 47, fanouts=(15, 10, 5), batch=1024, streams=8, hidden=256)
+dist = None
+if len(sys.argv) > 2 and sys.argv[2] == "rank":
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+t = Trainer(indptr, indices, feats, labels, 47, fanouts=(15, 10, 5), batch=1024, streams=8, hidden=256,
+            rank_path=dist is not None, dist=dist)
 t.set_nodes(np.random.default_rng(1).permutation(n))
 t.run(16)
 pr = cProfile.Profile()
@@ -29,4 +38,4 @@ pr.enable()
 t.run(steps, first_batch=16)
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
+st.sort_stats("tottime").print_stats(32)

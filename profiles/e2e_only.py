@@ -31,6 +31,7 @@ ap.add_argument("--rank-path", action="store_true",
                 help="the one-process-per-part code path (RCCL collectives with a world of one) instead of the fused "
                      "single-part one: what a rank of a multi-GPU job runs per step, minus the peers")
 ap.add_argument("--overlap", action="store_true")
+ap.add_argument("--tuned", action="store_true", help="use the recorded TunableOp GEMM selections (cslicer.train.use_tuned_gemms)")
 a = ap.parse_args()
 import torch  # noqa: E402
 
@@ -46,6 +47,9 @@ else:
 n = indptr.shape[0] - 1
 feats, labels = synthetic_node_data(n, 100, 47)
 fan = tuple(int(x) for x in a.fanout.split(","))
+if a.tuned:
+    from cslicer.train import use_tuned_gemms
+    print("tuned GEMM selections:", use_tuned_gemms(), file=sys.stderr)
 dist = None
 if a.rank_path:
     import torch.distributed as dist
