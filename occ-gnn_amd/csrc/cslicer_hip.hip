@@ -155,7 +155,6 @@ struct LArgs {
   uint32_t* dupout;           // [S][fcap0*P] scratch of k_dupseeds
   size_t fcap0;
   unsigned long long* rngend; // [S] the stream's mt19937 position after this round (per scratch set)
-  unsigned long long* snap;   // last layer: pinned HOST copy of rngend the round's snapshot goes to (else null)
   // CSL_FLAG_KEEP_CANDIDATES: raw neighbour_sample stream of this layer, [S][ccap] (debug export)
   uint32_t* candk;
   // CSL_MODE_GRAPH extras
@@ -746,9 +745,6 @@ __global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
   const uint32_t W = a.W;
   const unsigned long long C = (unsigned long long)F * W;
   const unsigned long long base = (unsigned long long)bx * SCT;
-  // the round's position snapshot (host pinned memory, written straight from here: this launch follows the round's
-  // last k_sample, after which nothing of the round reads the mt19937 ring any more)
-  if (a.snap && bx == 0 && threadIdx.x == 0) a.snap[s] = a.rngend[s];
   if (base >= C) return;
   const uint32_t nb = a.nbk[s];
   uint32_t* s_hist = s_dyn;
@@ -1808,7 +1804,6 @@ struct csl_engine {
   bool snap_pending[NSNAP] = {};
   uint64_t rounds_submitted = 0;
   uint64_t snap_next = 0;  // oldest round whose snapshot has not been applied yet
-  bool zero_copy = true;   // batch descriptors read, and position snapshots written, in pinned host memory by the kernels
   // capacities
   size_t fcap[CSL_MAX_LAYERS + 1];  // frontier capacity entering layer l
   size_t fcap_max = 0, ccap_max = 0;
@@ -2094,14 +2089,10 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
   if (rng_wait) HIPCHECK(hipStreamWaitEvent(st, rng_wait, 0));
   // the generator may only overwrite ring words below every stream's position
   const unsigned long long gen_lo = e->gen_hi > e->ring_words ? e->gen_hi - e->ring_words : 0;
-  // The minibatch descriptors (16 B per stream) are read by k_degree straight from the pinned host block: no H2D
-  // copy command (and its queue switch) in front of every round.  CSLICER_NO_ZEROCOPY=1 restores the copies.
-  BatchDesc* dd = e->zero_copy ? e->desc_host + (size_t)slot * S : e->desc_dev + (size_t)slot * S;
-  if (!e->zero_copy) {
-    HIPCHECK(hipMemcpyAsync(dd, e->desc_host + (size_t)slot * S, sizeof(BatchDesc) * S, hipMemcpyHostToDevice, st));
-    HIPCHECK(hipEventRecord(e->desc_event[slot], st));
-    e->desc_inflight[slot] = 1;
-  }
+  BatchDesc* dd = e->desc_dev + (size_t)slot * S;
+  HIPCHECK(hipMemcpyAsync(dd, e->desc_host + (size_t)slot * S, sizeof(BatchDesc) * S, hipMemcpyHostToDevice, st));
+  HIPCHECK(hipEventRecord(e->desc_event[slot], st));
+  e->desc_inflight[slot] = 1;
   csl_sample_meta* meta = e->meta + (size_t)slot * S;
   HIPCHECK(hipMemsetAsync(meta, 0, sizeof(csl_sample_meta) * (size_t)S, st));  // error bits and stale layer tables
   LArgs A[CSL_MAX_LAYERS];
@@ -2185,10 +2176,6 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     Timed t(e, KN_DEGREE, st);
     hipLaunchKernelGGL(k_degree, dim3(degree_blocks(0)), blk, 0, st, A[0], nodes_dev, (const BatchDesc*)dd);
   }
-  if (e->zero_copy) {  // the host may rewrite the slot's descriptors once this launch has read them
-    HIPCHECK(hipEventRecord(e->desc_event[slot], st));
-    e->desc_inflight[slot] = 1;
-  }
   for (int l = 0; l < L; l++) {
     const LArgs& a = A[l];
     const unsigned tiles_in = tiles_of(l);
@@ -2219,27 +2206,16 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
         int r2 = retire_snapshots(e, e->snap_round[k]);
         if (r2) return r2;
       }
-      if (!e->zero_copy) {
-        HIPCHECK(hipMemcpyAsync(e->snap_host + (size_t)k * S, a.rngend, sizeof(unsigned long long) * S,
-                                hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipEventRecord(e->snap_ev[k], st));
-      }
+      HIPCHECK(hipMemcpyAsync(e->snap_host + (size_t)k * S, a.rngend, sizeof(unsigned long long) * S,
+                              hipMemcpyDeviceToHost, st));
+      HIPCHECK(hipEventRecord(e->snap_ev[k], st));
       e->snap_round[k] = e->rounds_submitted;
       e->snap_pending[k] = true;
     }
     {
       Timed t(e, KN_SCATTER, st);
-      if (l == L - 1 && e->zero_copy) {
-        // k_scatter (the launch after the round's last k_sample) writes the snapshot into pinned host memory itself
-        LArgs b2 = a;
-        b2.snap = e->snap_host + (size_t)(e->rounds_submitted % csl_engine::NSNAP) * S;
-        hipLaunchKernelGGL(k_scatter, grid_scatter, blk, e->scatter_lds, st, b2);
-      } else {
-        hipLaunchKernelGGL(k_scatter, grid_scatter, blk, e->scatter_lds, st, a);
-      }
+      hipLaunchKernelGGL(k_scatter, grid_scatter, blk, e->scatter_lds, st, a);
     }
-    if (l == L - 1 && e->zero_copy)
-      HIPCHECK(hipEventRecord(e->snap_ev[e->rounds_submitted % csl_engine::NSNAP], st));
     {
       Timed t(e, KN_BUCKET, st);
       if (a.wl) hipLaunchKernelGGL(k_bucket<true>, grid_bucket, dim3(BT), 0, st, a);
@@ -2339,7 +2315,6 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   e->N = (uint32_t)cfg->num_nodes;
   e->E = (size_t)cfg->num_edges;
   HIPCHECK(hipSetDevice(cfg->device));
-  e->zero_copy = !getenv("CSLICER_NO_ZEROCOPY");
   e->nsets = (cfg->flags & CSL_FLAG_SERIAL_ROUNDS) ? 1 : (cfg->n_slots < CSL_MAX_SETS ? cfg->n_slots : CSL_MAX_SETS);
   for (int k = 0; k < e->nsets; k++) HIPCHECK(hipStreamCreateWithFlags(&e->streams[k], hipStreamNonBlocking));
   e->stream = e->streams[0];
