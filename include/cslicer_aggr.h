@@ -33,6 +33,10 @@ extern "C" {
 int csl_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
                      const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, void* stream);
 
+/* the same with the k-th listed row written to out[k] (rows != NULL): a send buffer of boundary partial sums */
+int csl_spmm_sum_compact_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
+                             const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, void* stream);
+
 /* grad_x[indices[e], :] += grad_out[q, :] for every edge e of row = rows ? rows[r] : r,
  * r in [0, n_rows); q = compact ? r : row (compact: grad_out holds only the listed rows). fp32 atomics. */
 int csl_spmm_sum_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
@@ -104,6 +108,13 @@ int csl_sage_cat_f32(const int32_t* indptr, const int32_t* indices, const int32_
 int csl_sage_cat_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, int64_t n,
                          const float* gcat, int64_t ldg, float* gx, int64_t ldx, int64_t n_src, int32_t H,
                          void* stream);
+
+/* gradient of the merged-sums form (indptr == NULL) of csl_sage_cat_f32: gx [n_x, H] and gagg [n_agg, H] (dense,
+ * either may be NULL) are ZEROED here, then gx[self_ids[r]] = gcat[r, 0:H) and
+ * gagg[owned[r]] = gcat[r, H:2H) / max(deg[r], 1); self_ids (where >= 0) and owned are unique.  H % 4 == 0. */
+int csl_sage_cat_rows_bwd_f32(const int32_t* self_ids, const int32_t* owned, const int32_t* deg, int64_t n,
+                              const float* gcat, int64_t ldg, float* gx, int64_t n_x, float* gagg, int64_t n_agg,
+                              int32_t H, void* stream);
 
 /* out[r, :] = (y == NULL || y[r, :] > 0) ? g[r, :] : 0 for r < n, zero rows for n <= r < n_pad;
  * colsum[c] = sum_r out[r, c]: ReLU backward + row padding of the GEMM operand + bias gradient in one pass

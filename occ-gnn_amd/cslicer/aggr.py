@@ -16,7 +16,7 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_sage_cat_f32", "csl_sage_cat_bwd_f32", "csl_relu_bwd_colsum_f32", "csl_softmax_ce_f32",
            "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch", "csl_adam_f32",
            "csl_scatter_add_rows_atomic_f32", "csl_gat_logits_fwd_f32", "csl_gat_logits_bwd_f32",
-           "csl_gat_logits_bwd_scratch"]
+           "csl_gat_logits_bwd_scratch", "csl_spmm_sum_compact_f32", "csl_sage_cat_rows_bwd_f32"]
 _ready = False
 
 
@@ -27,6 +27,8 @@ def _lib():
         vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int32
         L.csl_spmm_sum_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_spmm_sum_bwd_f32.argtypes = [vp, vp, vp, i64, vp, i64, i32, vp, i64, i32, vp]
+        L.csl_spmm_sum_compact_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, i32, vp]
+        L.csl_sage_cat_rows_bwd_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_gather_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_scatter_add_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_div_rows_f32.argtypes = [vp, i64, vp, i64, i32, vp]
@@ -96,6 +98,27 @@ def spmm_sum(indptr, indices, x, n_rows, rows=None, out=None):
     _chk(_lib().csl_spmm_sum_f32(_p(_i32(indptr)), _p(_i32(indices)), _p(rows) if rows is not None else C.c_void_p(0),
                                  n, _p(x), x.stride(0), _p(out), out.stride(0), H, _stream()), "csl_spmm_sum_f32")
     return out
+
+
+def spmm_sum_compact(indptr, indices, x, rows):
+    """[len(rows), H]: the k-th row is the sum-aggregate of CSR row rows[k] (a send buffer of boundary partial sums)."""
+    x = _f32(x)
+    out = torch.empty((rows.numel(), x.shape[1]), dtype=torch.float32, device=x.device)
+    _chk(_lib().csl_spmm_sum_compact_f32(_p(_i32(indptr)), _p(_i32(indices)), _p(_i32(rows)), rows.numel(), _p(x),
+                                         x.stride(0), _p(out), out.stride(0), x.shape[1], _stream()),
+         "csl_spmm_sum_compact_f32")
+    return out
+
+
+def sage_cat_rows_bwd(self_ids, owned, deg, gcat, n, n_x, n_agg, want_x=True, want_agg=True):
+    """Gradients of sage_cat's merged-sums form: (gx [n_x, H] or None, gagg [n_agg, H] or None), zero fill inside."""
+    gcat = _f32(gcat)
+    H = gcat.shape[1] // 2
+    gx = torch.empty((n_x, H), dtype=torch.float32, device=gcat.device) if want_x else None
+    gagg = torch.empty((n_agg, H), dtype=torch.float32, device=gcat.device) if want_agg else None
+    _chk(_lib().csl_sage_cat_rows_bwd_f32(_p(_i32(self_ids)), _p(_i32(owned)), _p(_i32(deg)), n, _p(gcat), gcat.stride(0),
+                                          _p(gx), n_x, _p(gagg), n_agg, H, _stream()), "csl_sage_cat_rows_bwd_f32")
+    return gx, gagg
 
 
 def spmm_sum_bwd(indptr, indices, grad_out, n_src, rows=None, compact=False, out=None):

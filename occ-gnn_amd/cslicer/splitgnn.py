@@ -167,13 +167,9 @@ class _SageFinish(torch.autograd.Function):
         gw = _weight_grad(gyp, cat)
         gx = gagg = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            gcat = gyp @ weight
-            if ctx.needs_input_grad[0]:
-                gx = torch.zeros((ctx.n_x, fin), dtype=torch.float32, device=gy.device)
-                aggr.scatter_add_rows_(gx, self_ids_in, gcat[:m, :fin])
-            if ctx.needs_input_grad[1]:
-                gagg = torch.zeros((ctx.n_agg, fin), dtype=torch.float32, device=gy.device)
-                aggr.scatter_add_rows_(gagg, owned, aggr.div_rows_(gcat[:m, fin:], deg))
+            # one launch: zero fill, self rows and degree-normalised owned rows (both index lists are unique)
+            gx, gagg = aggr.sage_cat_rows_bwd(self_ids_in, owned, deg, gyp @ weight, m, ctx.n_x, ctx.n_agg,
+                                              want_x=ctx.needs_input_grad[0], want_agg=ctx.needs_input_grad[1])
         return gx, gagg, gw, gb, None, None, None, None
 
 
@@ -538,8 +534,9 @@ class _RankAggregate(torch.autograd.Function):
         recv_counts = [0 if p == g else sl.to_ids[p].numel() for p in range(P)]
         H = x.shape[1]
         agg = torch.empty((sl.n_out, H), dtype=torch.float32, device=x.device)
-        aggr.spmm_sum(sl.indptr, sl.indices, x, sl.n_out, rows=sl.from_all, out=agg)
-        send_cat = aggr.gather_rows(agg, sl.from_all)
+        # the partial sums of the rows peers own go straight into the send buffer; their rows of `agg` are never
+        # written and never read (DistSageConv.finish takes the owned rows only)
+        send_cat = aggr.spmm_sum_compact(sl.indptr, sl.indices, x, sl.from_all)
         recv_cat, done = _RankAggregate._exchange(comm, send_cat, send_counts, recv_counts, overlap)
         aggr.spmm_sum(sl.indptr, sl.indices, x, sl.n_out, rows=sl.owned_out_nodes, out=agg)   # overlaps
         if done is not None:
@@ -560,8 +557,8 @@ class _RankAggregate(torch.autograd.Function):
         if done is not None:
             torch.cuda.current_stream().wait_event(done)
             back.record_stream(torch.cuda.current_stream())
-        g_remote = aggr.gather_rows(G, sl.from_all) + back   # grads of what this rank sent
-        aggr.spmm_sum_bwd(sl.indptr, sl.indices, g_remote, ctx.n_src, rows=sl.from_all, compact=True, out=gx)
+        # (the peer-owned rows of `agg` have no consumer on this rank: their gradient is what the peers send back)
+        aggr.spmm_sum_bwd(sl.indptr, sl.indices, back, ctx.n_src, rows=sl.from_all, compact=True, out=gx)
         return gx, None, None, None
 
 

@@ -51,12 +51,13 @@ __global__ __launch_bounds__(BLK) void k_spmm_sum(const int* __restrict__ indptr
                                                   const int* __restrict__ indices,
                                                   const int* __restrict__ rows, long long n_rows,
                                                   const float* __restrict__ x, long long ldx, float* __restrict__ out,
-                                                  long long ldo, int H, int vec_ok) {
+                                                  long long ldo, int H, int vec_ok, int compact) {
   constexpr int RPB = BLK / G;  // rows per block
   const int lane = threadIdx.x % G;
   const long long r = (long long)blockIdx.x * RPB + threadIdx.x / G;
   if (r >= n_rows) return;
   const long long row = rows ? rows[r] : r;
+  const long long orow = compact ? r : row;  // compact: the k-th listed row goes to out[k] (a send buffer)
   const long long e0 = indptr[row], e1 = indptr[row + 1];
   for (int c = lane * 4; c < H; c += G * 4) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -87,9 +88,9 @@ __global__ __launch_bounds__(BLK) void k_spmm_sum(const int* __restrict__ indptr
       add4(acc, vec_ok ? *reinterpret_cast<const float4*>(x + s0 * ldx + c) : ld4(x + s0 * ldx, c, H));
     }
     if (vec_ok) {
-      *reinterpret_cast<float4*>(out + row * ldo + c) = acc;
+      *reinterpret_cast<float4*>(out + orow * ldo + c) = acc;
     } else {
-      st4(out + row * ldo, c, H, acc);
+      st4(out + orow * ldo, c, H, acc);
     }
   }
 }
@@ -382,6 +383,28 @@ __global__ __launch_bounds__(BLK) void k_sage_cat(const int* __restrict__ indptr
     acc.x *= inv, acc.y *= inv, acc.z *= inv, acc.w *= inv;
     *reinterpret_cast<float4*>(out + c) = sv;
     *reinterpret_cast<float4*>(out + H + c) = acc;
+  }
+}
+
+// gradient of k_sage_cat's merged-sums form (several parts): plain stores, the index lists are unique
+template <int G>
+__global__ __launch_bounds__(BLK) void k_sage_cat_rows_bwd(const int* __restrict__ self_ids, const int* __restrict__ owned,
+                                                           const int* __restrict__ deg, long long n,
+                                                           const float* __restrict__ gcat, long long ldg,
+                                                           float* __restrict__ gx, float* __restrict__ gagg, int H) {
+  constexpr int RPB = BLK / G;
+  const int lane = threadIdx.x % G;
+  const long long r = (long long)blockIdx.x * RPB + threadIdx.x / G;
+  if (r >= n) return;
+  const long long sid = self_ids[r], ow = owned[r];
+  const long long d = deg[r];
+  const float inv = 1.0f / (float)(d > 1 ? d : 1);
+  for (int c = lane * 4; c < H; c += G * 4) {
+    const float4 a = *reinterpret_cast<const float4*>(gcat + r * ldg + c);
+    float4 b = *reinterpret_cast<const float4*>(gcat + r * ldg + H + c);
+    b.x *= inv, b.y *= inv, b.z *= inv, b.w *= inv;
+    if (gx && sid >= 0) *reinterpret_cast<float4*>(gx + sid * (long long)H + c) = a;
+    if (gagg) *reinterpret_cast<float4*>(gagg + ow * (long long)H + c) = b;
   }
 }
 
@@ -681,16 +704,32 @@ int done() { return hipGetLastError() == hipSuccess ? CSL_OK : CSL_E_HIP; }
 
 extern "C" {
 
-int csl_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
-                     const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, void* stream) {
+static int spmm_sum_impl(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
+                         const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, int compact, void* stream) {
   if (n_rows == 0) return CSL_OK;  // nothing to do: empty lists come with null pointers
-  if (n_rows < 0 || H < 1 || !indptr || !out || ldx < H || ldo < H) return CSL_E_INVALID;
+  if (n_rows < 0 || H < 1 || !indptr || !out || ldx < H || ldo < H || (compact && !rows)) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(x, ldx, out, ldo, H);
   DISPATCH_G(G, k_spmm_sum, n_rows, indptr, indices, rows,
-             (long long)n_rows, x, (long long)ldx, out, (long long)ldo, (int)H, v);
+             (long long)n_rows, x, (long long)ldx, out, (long long)ldo, (int)H, v, compact);
   return done();
 }
+
+int csl_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
+                     const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, void* stream) {
+  return spmm_sum_impl(indptr, indices, rows, n_rows, x, ldx, out, ldo, H, 0, stream);
+}
+
+int csl_spmm_sum_compact_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
+                             const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, void* stream) {
+  return spmm_sum_impl(indptr, indices, rows, n_rows, x, ldx, out, ldo, H, 1, stream);
+}
+
+// gradient of csl_sage_cat_f32's merged-sums form: gx [n_x, H] and gagg [n_agg, H] are zeroed here, then
+// gx[self_ids[r]] = gcat[r, 0:H) and gagg[owned[r]] = gcat[r, H:2H) / max(deg[r], 1) (both index lists are unique)
+int csl_sage_cat_rows_bwd_f32(const int32_t* self_ids, const int32_t* owned, const int32_t* deg, int64_t n,
+                              const float* gcat, int64_t ldg, float* gx, int64_t n_x, float* gagg, int64_t n_agg,
+                              int32_t H, void* stream);
 
 int csl_spmm_sum_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
                          const float* grad_out, int64_t ldg, int32_t compact, float* grad_x, int64_t ldx, int32_t H,
@@ -912,6 +951,22 @@ int csl_gat_logits_bwd_f32(const float* z, const float* attn_l, const float* att
   hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, C, g_attn_l);
   hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch + blocks * C, blocks, C,
                      g_attn_r);
+  return done();
+}
+
+int csl_sage_cat_rows_bwd_f32(const int32_t* self_ids, const int32_t* owned, const int32_t* deg, int64_t n,
+                              const float* gcat, int64_t ldg, float* gx, int64_t n_x, float* gagg, int64_t n_agg,
+                              int32_t H, void* stream) {
+  if (n < 0 || n_x < 0 || n_agg < 0 || H < 4 || H % 4 != 0) return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (gx && n_x > 0 && hipMemsetAsync(gx, 0, sizeof(float) * (size_t)n_x * H, st) != hipSuccess) return CSL_E_HIP;
+  if (gagg && n_agg > 0 && hipMemsetAsync(gagg, 0, sizeof(float) * (size_t)n_agg * H, st) != hipSuccess) return CSL_E_HIP;
+  if (n == 0 || (!gx && !gagg)) return CSL_OK;
+  if (!self_ids || !owned || !deg || !gcat || ldg < 2 * (int64_t)H || ldg % 4 != 0 || !aligned16(gcat) ||
+      (gx && !aligned16(gx)) || (gagg && !aligned16(gagg)))
+    return CSL_E_INVALID;
+  const int G = group_for(H);
+  DISPATCH_G(G, k_sage_cat_rows_bwd, n, self_ids, owned, deg, (long long)n, gcat, (long long)ldg, gx, gagg, (int)H);
   return done();
 }
 
