@@ -229,7 +229,13 @@ __device__ __forceinline__ bool last_block_of_stream(uint32_t* ticket, uint32_t 
   if (threadIdx.x == 0) {
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = t == expected - 1u;
-    if (t == expected - 1u) st_sc1(ticket, 0u);  // ready for the next launch (no other block touches it any more)
+    if (t == expected - 1u) {
+      st_sc1(ticket, 0u);  // ready for the next launch (no other block touches it any more)
+      // belt and braces: the scan only issues sc1 loads, which do not look at this CU's L1; the acquire
+      // (buffer_inv sc1, one wave of one block per stream) makes a plain load correct as well
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __syncthreads();
   return s_last != 0u;
