@@ -47,6 +47,14 @@ namespace {
 constexpr uint32_t UNSET = 0xFFFFFFFFu;
 
 constexpr int TN = 256;  // frontier nodes per tile == threads per block
+// launch bounds of the 256-thread kernels: the compiler is asked for 8 waves per SIMD.  Left alone it spends ~90
+// SGPRs on the by-value LArgs and the hardware then admits 7 blocks per CU, not 8 (MI355X_MICROARCH.md, residency);
+// with the bound it stays at 78: k_sample 193 -> 185 us, k_emit 183 -> 175 us.  -DCSL_OCC7 restores the old bound.
+#ifdef CSL_OCC7
+#define CSL_LB256 __launch_bounds__(256)
+#else
+#define CSL_LB256 __launch_bounds__(256, 8)
+#endif
 constexpr int CSL_MAX_SETS = 4;  // rounds in flight at once (HIP streams / scratch sets)
 constexpr int NW = TN / 64;
 // tuning constants (overridable with -D for sweeps; defaults measured best on MI355X, round 1)
@@ -506,7 +514,7 @@ __device__ __forceinline__ void degree_body(const LArgs& a, const uint32_t bx, c
   if (last_block_of_stream(a.ticket + 2 * s, nb_act)) scan_body<0>(a, (int)s);
 }
 
-__global__ __launch_bounds__(TN) void k_degree(LArgs a, const long long* __restrict__ nodes,
+__global__ CSL_LB256 void k_degree(LArgs a, const long long* __restrict__ nodes,
                                                const BatchDesc* __restrict__ desc) {
   uint32_t bx, s;
   if (!xcd_block(a, bx, s)) return;
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(TN) void k_degree(LArgs a, const long long* __restr
 // node's part mask, counts the per-node list memberships and the size of each
 // dedup bucket.  A block walks TPB consecutive tiles so its bucket histogram
 // (LDS) is flushed once per 1024 nodes.
-__global__ __launch_bounds__(TN) void k_sample(LArgs a) {
+__global__ CSL_LB256 void k_sample(LArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_bh[];  // [nb] bucket histogram
   uint32_t bx, s;
   if (!xcd_block(a, bx, s)) return;
@@ -743,7 +751,7 @@ __global__ __launch_bounds__(TN) void k_sample(LArgs a) {
 // sorts its SCT candidates by bucket in LDS first, so the pairs of one bucket
 // leave as one contiguous run (random 8-B stores run at ~90 G/s on this chip,
 // runs of 8-16 at 400-600 G/s: profiles/microbench/RESULTS.md).
-__global__ __launch_bounds__(TN) void k_scatter(LArgs a) {
+__global__ CSL_LB256 void k_scatter(LArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];  // hist[nb] loff[nb] gbase[nb] staged[2*SCT]
   uint32_t bx, s;
   if (!xcd_block(a, bx, s)) return;
@@ -1145,7 +1153,7 @@ __device__ __forceinline__ void count_tile(const LArgs& a, const uint32_t s, con
 #endif
 constexpr int EP = CSL_EP;  // candidate steps whose flag and id a k_emit thread preloads
 
-__global__ __launch_bounds__(TN) void k_emit(LArgs a) {
+__global__ CSL_LB256 void k_emit(LArgs a) {
   uint32_t tile, s;
   if (!xcd_block(a, tile, s)) return;
   const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
@@ -1628,14 +1636,14 @@ __device__ __forceinline__ void selfin_body(const LArgs& a, const uint32_t bx, c
     if (sp[j] != UNSET) ar[sp[j]] = r[j];
 }
 
-__global__ __launch_bounds__(TN) void k_selfin(LArgs a) {
+__global__ CSL_LB256 void k_selfin(LArgs a) {
   uint32_t bx, s;
   if (!xcd_block(a, bx, s)) return;
   selfin_body(a, bx, s);
 }
 // k_selfin of layer l and k_degree of layer l+1 both depend on layer l's k_emit only and are small: one launch.
 // Blocks [0, n_degree) are the next layer's k_degree (incl. its last-block scan), the rest this layer's k_selfin.
-__global__ __launch_bounds__(TN) void k_selfin_degree(LArgs a, LArgs nx, uint32_t n_degree) {
+__global__ CSL_LB256 void k_selfin_degree(LArgs a, LArgs nx, uint32_t n_degree) {
   uint32_t bx, s;
   if (blockIdx.x < n_degree) {
     if (!xcd_block_at(nx, blockIdx.x, n_degree, bx, s)) return;
