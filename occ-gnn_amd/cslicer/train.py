@@ -235,6 +235,8 @@ def use_tuned_gemms(path=TUNED_GEMMS):
         return False
     torch.cuda.tunable.enable(True)
     torch.cuda.tunable.tuning_enable(False)
+    if hasattr(torch.cuda.tunable, "write_file_on_exit"):
+        torch.cuda.tunable.write_file_on_exit(False)      # the recorded file is an input, never rewritten
     torch.cuda.tunable.set_filename(path)
     return True
 

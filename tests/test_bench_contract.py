@@ -63,7 +63,9 @@ def test_bench_flags_parse():
                      ["--mode", "graph"],
                      ["--fanout", "10,10,10", "--e2e-model", "gat", "--e2e-hidden", "32"],
                      ["--no-e2e-multi", "--e2e-timeout", "30"],
-                     ["--serial-rounds", "--no-cpu-baseline", "--no-kernel-timing", "--e2e-steps", "0"]):
+                     ["--serial-rounds", "--no-cpu-baseline", "--no-kernel-timing", "--e2e-steps", "0"],
+                     ["--no-compat", "--no-tuned-gemms", "--e2e-streams", "16", "--same-batch"],
+                     ["--gpus", "2", "--selftest-dist", "ok"]):
             sys.argv = ["bench.py"] + argv
             a = mod.parse()
             assert a.steps > 0 and a.mode in ("strict", "graph")
