@@ -46,8 +46,13 @@ def _free_port():
 
 
 def _table(n, world, seed=11):
-    """A node -> part table that is NOT v % world (the METIS-map use case)."""
-    return np.random.default_rng(seed).integers(0, world, size=n).astype(np.int32)
+    """A node -> part table that is NOT v % world (the METIS-map use case).  With three parts the last one owns
+    only ~0.5 % of the nodes: most minibatches then hold no seed of that rank and its slices are nearly empty
+    (empty lists, zero-row GEMMs, a rank without a loss term: it must still join every collective)."""
+    rng = np.random.default_rng(seed)
+    if world == 3:
+        return rng.choice(3, size=n, p=[0.55, 0.445, 0.005]).astype(np.int32)
+    return rng.integers(0, world, size=n).astype(np.int32)
 
 
 def _rank_main(rank, world, port, q, overlap=False, kind="sage", table=False):
@@ -95,13 +100,15 @@ def _rank_body(rank, world, q, overlap, kind, dist, table=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap,kind,table", [(False, "sage", False), (True, "sage", False), (False, "gat", False),
-                                                (False, "sage", True), (True, "sage", True)],
-                         ids=["sequential", "side-stream-overlap", "gat", "partition-table", "partition-table-overlap"])
-def test_two_ranks_match_single_process_two_parts(overlap, kind, table):
+@pytest.mark.parametrize("overlap,kind,table,world", [(False, "sage", False, 2), (True, "sage", False, 2),
+                                                      (False, "gat", False, 2), (False, "sage", True, 2),
+                                                      (True, "sage", True, 2), (False, "sage", True, 3),
+                                                      (False, "gat", True, 3)],
+                         ids=["sequential", "side-stream-overlap", "gat", "partition-table", "partition-table-overlap",
+                              "three-ranks-one-nearly-empty", "three-ranks-one-nearly-empty-gat"])
+def test_two_ranks_match_single_process_two_parts(overlap, kind, table, world):
     import torch.multiprocessing as mp
     from cslicer import _abi, splitgnn
-    world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -117,8 +124,8 @@ def test_two_ranks_match_single_process_two_parts(overlap, kind, table):
     # single-process reference: same engine config, both parts in this process
     indptr, indices, feats, labels, perm = _task()
     dev = torch.device("cuda", 0)
-    eng = _abi.Engine(indptr, indices, n_parts=2, fanouts=(10, 5), max_batch=128, n_streams=2, n_slots=2,
-                      mode=_abi.MODE_GRAPH, workload=_table(indptr.shape[0] - 1, 2) if table else None)
+    eng = _abi.Engine(indptr, indices, n_parts=world, fanouts=(10, 5), max_batch=128, n_streams=2, n_slots=2,
+                      mode=_abi.MODE_GRAPH, workload=_table(indptr.shape[0] - 1, world) if table else None)
     eng.set_nodes(perm)
     torch.manual_seed(0)
     if kind == "gat":
@@ -132,10 +139,10 @@ def test_two_ranks_match_single_process_two_parts(overlap, kind, table):
         eng.submit_round(r * 2, 128, 2, slot=r & 1)
         for s in range(2):
             sl = splitgnn.slices_of(eng, s, r & 1)
-            x = {g: ft[sl[1][g].in_nodes.long()] for g in range(2)}
+            x = {g: ft[sl[1][g].in_nodes.long()] for g in range(world)}
             out = model.forward_parts(sl, x)
             loss = 0
-            for g in range(2):
+            for g in range(world):
                 seeds = sl[0][g].out_nodes[sl[0][g].owned_out_nodes.long()].long()
                 loss = loss + torch.nn.functional.cross_entropy(out[g], lt[seeds], reduction="sum")
             loss = loss / 128
