@@ -68,7 +68,7 @@ constexpr int NW = TN / 64;
 #define CSL_QMEAN 2048
 #endif
 #ifndef CSL_SCT
-#define CSL_SCT 8192
+#define CSL_SCT 4096  // (8192 until the kernels ran at 8 blocks per CU: profiles/SWEEP_r2.md)
 #endif
 #ifndef CSL_SU
 #define CSL_SU 1
@@ -915,7 +915,7 @@ __device__ __forceinline__ uint32_t ht_insert(uint32_t* h_key, uint32_t val) {
 }
 
 #ifndef CSL_BPB
-#define CSL_BPB 2
+#define CSL_BPB 4
 #endif
 constexpr int BPB = CSL_BPB;  // buckets a block resolves one after the other; the next one's entries are in flight meanwhile
 
