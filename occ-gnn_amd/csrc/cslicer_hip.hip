@@ -521,6 +521,15 @@ __global__ CSL_LB256 void k_degree(LArgs a, const long long* __restrict__ nodes,
   degree_body(a, bx, s, gridDim.x / (8u * ((a.S + 7u) >> 3)), nodes, desc);
 }
 
+// mt19937's output tempering (applied by k_mt19937_temper)
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
 // ---- k_sample: second half of neighbour_sample (slicer.cpp:10-21) + the
 // bookkeeping side of the slice_layer inner loop (slicer.cpp:31-44): writes the
 // candidate stream, ORs the owner part of each sampled neighbour into the
@@ -1661,44 +1670,79 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t l) {
   const uint32_t y = (u & 0x80000000u) | (l & 0x7fffffffu);
   return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
-#ifndef CSL_MT_THREADS
-#define CSL_MT_THREADS 256
-#endif
-constexpr int MTT = CSL_MT_THREADS;  // 256 lanes per 227-word phase beat one wave (5.2 ms vs 1.9 ms per chunk)
+constexpr int MTT = 256;
 
-// (tried: one wave instead of 256 lanes -> 5.2 ms per 2 M-word chunk instead of 1.9 ms; an LDS-only
-// barrier instead of __syncthreads() -> no change: the three dependent LDS round trips per 624 words
-// set the pace, ~1.1 G words/s, about five times what the slicer consumes)
+// The recurrence x[n+624] = x[n+397] ^ twist(x[n], x[n+1]) lets 227 words be computed side by side.  Lane i < 227 owns
+// the words i, 227+i and 454+i of every 624-word block: the new word 227+i needs the new word i, and 454+i the new
+// 227+i -- the lane's own results -- and everything else a lane reads belongs to the PREVIOUS block.  So one block is
+// one LDS round trip (the other lanes' old words) and ONE workgroup barrier, not three dependent phases (round 1's
+// kernel: 1.03 G words/s, and at S <= 16 the slicer waited for it: profiles/small_s_trace).  The barrier does not
+// wait for the ring stores (s_waitcnt lgkmcnt only).  The one workgroup is ALU-issue-bound, so it stores the words
+// untempered; k_mt19937_temper, a chip-wide pass behind it on the same HIP stream, applies the output function in place
+// (k_sample is issue-bound too: tempering each draw there cost it 7 %).  Word 623 needs the new word 0: lane 169 recomputes that one.
 __global__ __launch_bounds__(MTT) void k_mt19937_fill(uint32_t* state, uint32_t* ring, unsigned long long ring_mask,
                                                      unsigned long long pos0, uint32_t nblocks) {
-  __shared__ uint32_t buf[2][624];
+  __shared__ uint32_t buf[2][624 + 8];
   const uint32_t t = threadIdx.x;
   for (uint32_t i = t; i < 624; i += MTT) buf[0][i] = state[i];
   __syncthreads();
+  const bool act = t < 227, has2 = t < 170;
+  uint32_t v0 = 0, v1 = 0, v2 = 0;
+  if (act) {
+    v0 = buf[0][t];
+    v1 = buf[0][227 + t];
+    if (has2) v2 = buf[0][454 + t];
+  }
   uint32_t cur = 0;
+  const uint32_t m = (uint32_t)ring_mask;
+  uint32_t p = (uint32_t)pos0 + t;
   for (uint32_t blk = 0; blk < nblocks; blk++) {
     const uint32_t* A = buf[cur];
     uint32_t* B = buf[cur ^ 1];
-    for (uint32_t i = t; i < 227; i += MTT) B[i] = A[i + 397] ^ mt_twist(A[i], A[i + 1]);
-    __syncthreads();
-    for (uint32_t i = t; i < 227; i += MTT) B[227 + i] = B[i] ^ mt_twist(A[227 + i], A[228 + i]);
-    __syncthreads();
-    for (uint32_t i = t; i < 169; i += MTT) B[454 + i] = B[227 + i] ^ mt_twist(A[454 + i], A[455 + i]);
-    if (t == MTT - 1) B[623] = B[396] ^ mt_twist(A[623], B[0]);
-    __syncthreads();
-    const unsigned long long base = pos0 + (unsigned long long)blk * 624ull;
-    for (uint32_t i = t; i < 624; i += MTT) {
-      uint32_t y = B[i];
-      y ^= y >> 11;
-      y ^= (y << 7) & 0x9d2c5680u;
-      y ^= (y << 15) & 0xefc60000u;
-      y ^= y >> 18;
-      ring[(base + i) & ring_mask] = y;
+    if (act) {
+      const uint32_t a1 = A[t + 1], a397 = A[t + 397], a228 = A[t + 228];
+      const uint32_t a455 = t < 169 ? A[t + 455] : 0u;
+      // the new word 0, for word 623 (every lane reads the three words -- LDS broadcasts -- in the same round trip:
+      // a branch for lane 169 alone would cost its wave, and with it the barrier, a second one)
+      const uint32_t b0 = A[397] ^ mt_twist(A[0], A[1]);
+      const uint32_t n0 = a397 ^ mt_twist(v0, a1);
+      const uint32_t n1 = n0 ^ mt_twist(v1, a228);
+      const uint32_t n2 = n1 ^ mt_twist(v2, t == 169 ? b0 : a455);
+      B[t] = n0;
+      B[227 + t] = n1;
+      if (has2) B[454 + t] = n2;
+      v0 = n0;
+      v1 = n1;
+      v2 = n2;
+      // (32-bit index arithmetic is exact: the ring has at most 2^31 words)
+      ring[p & m] = n0;
+      ring[(p + 227u) & m] = n1;
+      if (has2) ring[(p + 454u) & m] = n2;
+      p += 624u;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     cur ^= 1;
   }
   __syncthreads();
   for (uint32_t i = t; i < 624; i += MTT) state[i] = buf[cur][i];
+}
+
+__global__ __launch_bounds__(256) void k_mt19937_temper(uint32_t* ring, uint32_t m, uint32_t p0, uint32_t nwords) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nwords; i += gridDim.x * 256u)
+    ring[(p0 + i) & m] = mt_temper(ring[(p0 + i) & m]);
+}
+
+// one generator chunk: nblocks * 624 words from position pos0 on `st`
+void launch_mt_fill(hipStream_t st, uint32_t* state, uint32_t* ring, uint64_t ring_words, uint64_t pos0, uint32_t nblocks) {
+  hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(MTT), 0, st, state, ring, (unsigned long long)(ring_words - 1),
+                     (unsigned long long)pos0, nblocks);
+  uint64_t nwords = (uint64_t)nblocks * 624u;
+  if (nwords > ring_words) {  // (csl_rng_peek may run the generator over more than one lap: only the last lap is left)
+    pos0 += nwords - ring_words;
+    nwords = ring_words;
+  }
+  hipLaunchKernelGGL(k_mt19937_temper, dim3((unsigned)((nwords + 1023u) / 1024u)), dim3(256), 0, st, ring,
+                     (uint32_t)(ring_words - 1), (uint32_t)pos0, (uint32_t)nwords);
 }
 
 // packs the reference's int64 CSR into rowinfo / u32 indices on the device
@@ -2046,8 +2090,7 @@ int ensure_rng(csl_engine* e, hipEvent_t* wait, uint64_t* safe_hi) {
       if (nblocks == 0) break;  // the ring is full relative to the slowest stream
       {
         Timed t(e, KN_MT, e->rng_stream);
-        hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(MTT), 0, e->rng_stream, e->mt_state, e->ring,
-                           (unsigned long long)(e->ring_words - 1), (unsigned long long)e->gen_hi, nblocks);
+        launch_mt_fill(e->rng_stream, e->mt_state, e->ring, e->ring_words, e->gen_hi, nblocks);
       }
       HIPCHECK(hipGetLastError());
       e->gen_hi += (uint64_t)nblocks * 624ull;
@@ -2489,6 +2532,7 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   }
   // ---- rng
   const uint32_t lg = cfg->rng_ring_log2 ? cfg->rng_ring_log2 : 26;
+  if (lg > 31) return fail(CSL_E_INVALID, "rng_ring_log2=%u: at most 31", lg);
   e->ring_words = 1ull << lg;
   if (e->ring_words < 4 * e->worst_draws + 2 * 624)
     return fail(CSL_E_INVALID, "rng_ring_log2=%u too small: one round may draw %llu words", lg,
@@ -2897,8 +2941,7 @@ int csl_rng_peek(csl_engine* e, uint64_t pos, uint32_t* dst, int64_t n) {
   while (e->gen_hi < pos + (uint64_t)n) {
     uint64_t words = pos + (uint64_t)n - e->gen_hi;
     uint32_t nblocks = (uint32_t)((words + 623) / 624);
-    hipLaunchKernelGGL(k_mt19937_fill, dim3(1), dim3(MTT), 0, e->rng_stream, e->mt_state, e->ring,
-                       (unsigned long long)(e->ring_words - 1), (unsigned long long)e->gen_hi, nblocks);
+    launch_mt_fill(e->rng_stream, e->mt_state, e->ring, e->ring_words, e->gen_hi, nblocks);
     e->gen_hi += (uint64_t)nblocks * 624ull;
     HIPCHECK(hipStreamSynchronize(e->rng_stream));
   }

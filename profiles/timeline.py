@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch timeline of the last engine round in a rocprofv3 kernel trace.
-usage: python3 profiles/timeline.py <dir containing *_kernel_trace.csv> [n_launches_per_round]"""
+usage: python3 profiles/timeline.py <dir containing *_kernel_trace.csv> [index of the round, default -2]"""
 import csv
 import glob
 import sys
@@ -9,9 +9,15 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))
         if "k_" in r["Kernel_Name"] and "pack" not in r["Kernel_Name"] and "mt19937" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a round starts at k_seeds
-starts = [i for i, r in enumerate(rows) if "k_seeds" in r["Kernel_Name"]]
-last = rows[starts[-1]:]
+# a round starts at k_degree (layer 0; the later layers' degree pass is k_selfin_degree); with rounds in flight on
+# several HIP streams, keep the launches of the stream that runs the last complete round
+starts = [i for i, r in enumerate(rows) if "::k_degree(" in r["Kernel_Name"]]
+which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
+qid = rows[starts[which]].get("Queue_Id")
+last = [r for r in rows[starts[which]:] if r.get("Queue_Id") == qid]
+nxt = [i for i, r in enumerate(last) if i and "::k_degree(" in r["Kernel_Name"]]
+if nxt:
+    last = last[:nxt[0]]
 t0 = int(last[0]["Start_Timestamp"])
 tot = 0
 for r in last:
