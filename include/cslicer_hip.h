@@ -37,7 +37,7 @@ extern "C" {
 
 #define CSL_MAX_PARTS 8
 #define CSL_MAX_LAYERS 4
-#define CSL_ABI_VERSION 3
+#define CSL_ABI_VERSION 4
 
 enum {
   CSL_OK = 0,
@@ -75,7 +75,14 @@ enum {
   CSL_INDPTR = 7,           /* graph mode: CSR row pointers over out_nodes, len(out_nodes)+1 per part */
   CSL_INDICES = 8,          /* graph mode: local index into in_nodes of every edge's source */
   CSL_OWNED_DEGREE = 9,     /* graph mode: edges of each owned out node over ALL parts (mean divisor) */
-  CSL_NUM_LISTS = 10
+  /* graph mode + CSL_FLAG_TRANSPOSE, every layer but the deepest: the slice by SOURCE, for the backward pass of the
+   * aggregation as a gather (each source-gradient row written once: no atomics, nothing to pre-zero).
+   * For in node u of slice g, entries [t_indptr[u], t_indptr[u+1]) of t_indices hold, ascending: ~r (negative) when u
+   * is the self source of owned out node r (self_ids_in/self_ids_out), then the out row r of every edge u -> r of the
+   * slice's CSR (a row twice when the edge was sampled twice). */
+  CSL_T_INDPTR = 10,        /* len(in_nodes)+1 per part */
+  CSL_T_INDICES = 11,       /* len(indices) + len(self_ids_in) per part */
+  CSL_NUM_LISTS = 12
 };
 
 /* csl_config.mode */
@@ -132,7 +139,10 @@ enum {
   /* keep every layer's raw neighbour_sample stream (slicer.cpp:6-22: the node itself, then its sampled
    * neighbours, sampled self loops included) per result slot for csl_copy_candidates; test/debug only:
    * costs n_slots x n_layers x n_streams x (largest candidate capacity) x 4 bytes of device memory */
-  CSL_FLAG_KEEP_CANDIDATES = 2
+  CSL_FLAG_KEEP_CANDIDATES = 2,
+  /* CSL_MODE_GRAPH: also emit the slices by source (CSL_T_INDPTR / CSL_T_INDICES) for every layer but the deepest
+   * (whose sources are input features: no gradient flows to them) */
+  CSL_FLAG_TRANSPOSE = 4
 };
 
 typedef struct {

@@ -49,7 +49,8 @@ class Slice(object):
     """One BiPartite of graph mode on the device: int32 tensors that alias the engine's arena."""
 
     __slots__ = ("part", "n_parts", "in_nodes", "out_nodes", "indptr", "indices", "owned_out_nodes",
-                 "self_ids_in", "owned_degree", "from_ids", "to_ids", "from_all", "to_all", "n_in", "n_out", "n_owned")
+                 "self_ids_in", "owned_degree", "from_ids", "to_ids", "from_all", "to_all", "n_in", "n_out", "n_owned",
+                 "t_indptr", "t_indices")
 
 
 def _arena_tensors(eng, device):
@@ -101,6 +102,8 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
             s.owned_out_nodes = seg(_abi.OWNED_OUT_NODES, g)
             s.self_ids_in = seg(_abi.SELF_IDS_IN, g)
             s.owned_degree = seg(_abi.OWNED_DEGREE, g)
+            # the slice by source (engine flag FLAG_TRANSPOSE; empty otherwise and for the deepest layer)
+            s.t_indptr, s.t_indices = seg(_abi.T_INDPTR, g), seg(_abi.T_INDICES, g)
             f0, t0 = int(lm.off[_abi.FROM_IDS][g]), int(lm.off[_abi.TO_IDS][g])
             s.from_ids = [seg(_abi.FROM_IDS, g, f0 + int(lm.pair_off[0][g][p]), f0 + int(lm.pair_off[0][g][p + 1]))
                           for p in range(P)]

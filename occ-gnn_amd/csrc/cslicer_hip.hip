@@ -169,6 +169,7 @@ struct LArgs {
   uint32_t graph;             // 0 strict, 1 graph
   uint8_t* ecnt;              // [S][fcap*P] edges of node i whose source is owned by g
   uint32_t* srcpos;           // [S][ccap]   position of the first occurrence of an edge's source
+  uint32_t* tcur;             // [S][ccap]   CSL_FLAG_TRANSPOSE, this layer: edges (+ self entry) per in node, then fill cursors; else null
 };
 
 constexpr uint32_t SELF_BIT = 0x80000000u;
@@ -387,6 +388,8 @@ __device__ __forceinline__ void scan_body(const LArgs& a, const int s) {
         case CSL_FROM_IDS: return a.graph ? pair_sum(g, true) : s_tot[K_FROM(P, g)];
         case CSL_INDPTR: return a.graph ? (F ? s_tot[K_OUT(P, g)] + 1 : 0u) : 0u;
         case CSL_INDICES: return a.graph ? s_tot[K_ECNT(P, g)] : 0u;
+        case CSL_T_INDPTR: return a.tcur ? (F ? s_tot[K_IN(P, g)] + 1 : 0u) : 0u;
+        case CSL_T_INDICES: return a.tcur ? s_tot[K_ECNT(P, g)] + s_tot[K_SELF(P, g)] : 0u;
         default: return a.graph ? s_tot[K_OWNED(P, g)] : 0u;  // CSL_OWNED_DEGREE
       }
     };
@@ -1261,6 +1264,7 @@ __global__ CSL_LB256 void k_emit(LArgs a) {
       if (fe && ((a.pmask >> g) & 1u)) {
         const uint32_t p = s_run[b][1 + g] + rE + BYTESUM(s_wc[b][1 + g] & below);  // local index inside slice g's in_nodes
         in_list[s_mo[0][g] + p] = (int)val;
+        if (a.tcur) a.tcur[(size_t)s * a.ccap + s_mo[0][g] + p] = 0;  // k_graph counts the in node's edges here
         // DuplicateRemover::replace's lookup value (mask[v]-1): read back by k_selfin for candidates whose
         // node is in the frontier (flag bit 5) and by k_graph for every edge
         if (a.graph || (fl & 32u)) a.crank[cbase + (c0 + j) * TN + n] = p;
@@ -1616,8 +1620,94 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
       }
     }
     ar[a.list_base[CSL_INDICES] + m.off[CSL_INDICES][g] + pos] = (int)rank;
+    if (a.tcur) atomicAdd(&a.tcur[(size_t)s * a.ccap + m.off[CSL_IN_NODES][g] + rank], 1u);
+  }
+  // the slice by source (k_transpose) also lists the node's self entry: the in-node rank k_selfin stores
+  if (a.tcur && ((a.pmask >> to) & 1u)) {
+    const uint32_t selfrank = a.crank[(size_t)s * a.ccap + a.firstpos[s * a.fcap + i]];
+    atomicAdd(&a.tcur[(size_t)s * a.ccap + m.off[CSL_IN_NODES][to] + selfrank], 1u);
   }
 #undef TB
+}
+
+// ---- k_transpose (CSL_FLAG_TRANSPOSE): slice g of stream s by SOURCE, one block per (s, g).  k_graph left the number of
+// entries of every in node in tcur; here: exclusive scan -> t_indptr (tcur becomes the fill cursor), fill from the
+// slice's CSR and self lists (atomic cursors: any order), then every in node's short list is sorted, which makes the
+// result deterministic: ~r of the self entry first, then the out rows ascending.  A minibatch layer has ~10^5 entries:
+// one block per slice keeps this at one launch per layer, off the sampling chain's critical path.
+constexpr int TR_T = 1024;
+__global__ __launch_bounds__(TR_T) void k_transpose(LArgs a) {
+  const uint32_t s = blockIdx.x / a.P, g = blockIdx.x - s * a.P;
+  if (!((a.pmask >> g) & 1u)) return;
+  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
+  if (F == 0) return;
+  const csl_layer_meta& m = a.meta[s].layer[a.layer];
+  int* ar = a.arena + (size_t)s * a.arena_stride;
+  const uint32_t n_in = m.off[CSL_IN_NODES][g + 1] - m.off[CSL_IN_NODES][g];
+  const uint32_t n_out = m.off[CSL_OUT_NODES][g + 1] - m.off[CSL_OUT_NODES][g];
+  const uint32_t n_self = m.off[CSL_SELF_IDS_IN][g + 1] - m.off[CSL_SELF_IDS_IN][g];
+  uint32_t* cnt = a.tcur + (size_t)s * a.ccap + m.off[CSL_IN_NODES][g];
+  int* tptr = ar + a.list_base[CSL_T_INDPTR] + m.off[CSL_T_INDPTR][g];
+  int* trow = ar + a.list_base[CSL_T_INDICES] + m.off[CSL_T_INDICES][g];
+  const int* indptr = ar + a.list_base[CSL_INDPTR] + m.off[CSL_INDPTR][g];
+  const int* indices = ar + a.list_base[CSL_INDICES] + m.off[CSL_INDICES][g];
+  const int* self_in = ar + a.list_base[CSL_SELF_IDS_IN] + m.off[CSL_SELF_IDS_IN][g];
+  const int* self_out = ar + a.list_base[CSL_SELF_IDS_OUT] + m.off[CSL_SELF_IDS_OUT][g];
+  __shared__ uint32_t s_w[TR_T / 64];
+  __shared__ uint32_t s_total;
+  const uint32_t t = threadIdx.x, w = t >> 6;
+  // exclusive scan, a contiguous chunk per thread
+  const uint32_t chunk = (n_in + TR_T - 1) / TR_T;
+  const uint32_t lo = t * chunk < n_in ? t * chunk : n_in;
+  const uint32_t hi = lo + chunk < n_in ? lo + chunk : n_in;
+  uint32_t sum = 0;
+  for (uint32_t u = lo; u < hi; u++) sum += cnt[u];
+  uint32_t wtot;
+  uint32_t run = wave_excl_scan(sum, wtot);
+  if (lane_id() == 0) s_w[w] = wtot;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t r = 0;
+    for (int k = 0; k < TR_T / 64; k++) {
+      const uint32_t x = s_w[k];
+      s_w[k] = r;
+      r += x;
+    }
+    s_total = r;
+  }
+  __syncthreads();
+  run += s_w[w];
+  for (uint32_t u = lo; u < hi; u++) {
+    const uint32_t c = cnt[u];
+    tptr[u] = (int)run;
+    cnt[u] = run;
+    run += c;
+  }
+  if (t == 0) tptr[n_in] = (int)s_total;
+  __syncthreads();  // (block-scope visibility of the cursors)
+  // fill
+  for (uint32_t k = t; k < n_self; k += TR_T) {
+    const int u = self_in[k];
+    if (u >= 0) trow[atomicAdd(&cnt[u], 1u)] = ~self_out[k];
+  }
+  for (uint32_t r = t; r < n_out; r += TR_T) {
+    const int e1 = indptr[r + 1];
+    for (int e = indptr[r]; e < e1; e++) trow[atomicAdd(&cnt[indices[e]], 1u)] = (int)r;
+  }
+  __syncthreads();
+  // sort every in node's entries (insertion sort: lists hold one or two entries on average)
+  for (uint32_t u = t; u < n_in; u += TR_T) {
+    const int j0 = tptr[u], j1 = tptr[u + 1];
+    for (int j = j0 + 1; j < j1; j++) {
+      const int x = trow[j];
+      int k = j - 1;
+      while (k >= j0 && trow[k] > x) {
+        trow[k + 1] = trow[k];
+        k--;
+      }
+      trow[k + 1] = x;
+    }
+  }
 }
 
 // ---- k_selfin: self_ids_in (replace(self_ids_in), bipartite.cpp:6): the
@@ -1877,6 +1967,7 @@ struct csl_engine {
   uint32_t* crank = nullptr;
   uint8_t* ecnt = nullptr;
   uint32_t* srcpos = nullptr;
+  uint32_t* tcur = nullptr;
   uint32_t* dupflag = nullptr;   // [nsets][S]
   uint32_t* seedrep = nullptr;   // [nsets][S][fcap0]
   uint32_t* dupfirst = nullptr;  // [nsets][S][fcap0*P]
@@ -2210,6 +2301,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.graph = e->cfg.mode == CSL_MODE_GRAPH ? 1u : 0u;
     a.ecnt = e->ecnt ? e->ecnt + sF * e->P : nullptr;
     a.srcpos = e->srcpos ? e->srcpos + sC : nullptr;
+    a.tcur = (e->tcur && l < L - 1) ? e->tcur + sC : nullptr;
     a.dupflag = e->dupflag + (size_t)set * S;
     a.fcap0 = e->fcap[0];
     a.seedrep = e->seedrep + (size_t)set * S * e->fcap[0];
@@ -2303,6 +2395,8 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
       Timed t(e, KN_SELFIN, st);
       hipLaunchKernelGGL(k_selfin, dim3(n_selfin), blk, 0, st, a);
     }
+    // (after k_selfin: the self entries come from self_ids_in)
+    if (a.tcur) hipLaunchKernelGGL(k_transpose, dim3((unsigned)(S * e->P)), dim3(TR_T), 0, st, a);
   }
   HIPCHECK(hipGetLastError());
   for (int s = 0; s < n_batches && s < S; s++) e->pos_ub[s] += e->worst_draws;
@@ -2336,7 +2430,7 @@ void csl_destroy(csl_engine* e) {
   void* ptrs[] = {e->rowinfo, e->off32, e->indices, e->wl,      e->nodes, e->seedbuf, e->ring,  e->mt_state, e->rngpos,
                   e->rngbase, e->ninfo,   e->hasedge, e->selfpos, e->firstpos, e->cand, e->cflag, e->crank,
                   e->queue,   e->nbk,     e->bcnt,    e->bcur,    e->tcnt,     e->fsize, e->meta, e->desc_dev,
-                  e->ecnt,    e->srcpos,  e->acc,     e->dupflag, e->seedrep, e->dupfirst, e->dupout, e->rngend,
+                  e->ecnt,    e->srcpos,  e->tcur, e->acc,     e->dupflag, e->seedrep, e->dupfirst, e->dupout, e->rngend,
                   e->candk,   e->boff,    e->ticket};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -2447,6 +2541,7 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   if (cfg->mode == CSL_MODE_GRAPH) {
     DMALLOC(e->ecnt, e->nsets * (size_t)S * e->fcap_max * P);
     DMALLOC(e->srcpos, e->nsets * (size_t)S * e->ccap_max);
+    if ((cfg->flags & CSL_FLAG_TRANSPOSE) && L > 1) DMALLOC(e->tcur, e->nsets * (size_t)S * e->ccap_max);
   }
   DMALLOC(e->queue, e->nsets * (size_t)S * e->ccap_max);
   DMALLOC(e->dupflag, e->nsets * (size_t)S);
@@ -2496,7 +2591,7 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
     cap[CSL_SELF_IDS_OUT] = F;
     cap[CSL_TO_IDS] = F;
     cap[CSL_FROM_IDS] = outs;
-    cap[CSL_INDPTR] = cap[CSL_INDICES] = cap[CSL_OWNED_DEGREE] = 0;
+    cap[CSL_INDPTR] = cap[CSL_INDICES] = cap[CSL_OWNED_DEGREE] = cap[CSL_T_INDPTR] = cap[CSL_T_INDICES] = 0;
     if (cfg->mode == CSL_MODE_GRAPH) {
       // every owned node is an in node and an out node of its slice
       size_t outs_g = F * (size_t)(P < (int)f + 1 ? P : (int)f + 1);
@@ -2508,6 +2603,10 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
       cap[CSL_INDPTR] = outs_g + (size_t)P;
       cap[CSL_INDICES] = edges;
       cap[CSL_OWNED_DEGREE] = F;
+      if ((cfg->flags & CSL_FLAG_TRANSPOSE) && l < L - 1) {
+        cap[CSL_T_INDPTR] = edges + F + (size_t)P;
+        cap[CSL_T_INDICES] = edges + F;
+      }
     }
     size_t o = 0;
     for (int k = 0; k < CSL_NUM_LISTS; k++) {
@@ -2563,6 +2662,8 @@ int csl_create(const csl_config* cfg, csl_engine** out) {
   if (cfg->n_slots < 1 || cfg->n_slots > 16) return fail(CSL_E_INVALID, "n_slots must be 1..16");
   if (cfg->max_batch < 1) return fail(CSL_E_INVALID, "max_batch must be >= 1");
   if (cfg->mode != CSL_MODE_STRICT && cfg->mode != CSL_MODE_GRAPH) return fail(CSL_E_INVALID, "unknown mode %d", cfg->mode);
+  if ((cfg->flags & CSL_FLAG_TRANSPOSE) && cfg->mode != CSL_MODE_GRAPH)
+    return fail(CSL_E_INVALID, "CSL_FLAG_TRANSPOSE needs CSL_MODE_GRAPH (strict mode has no edges to transpose)");
   if (cfg->part_mask >> cfg->n_parts) return fail(CSL_E_INVALID, "part_mask 0x%x names parts beyond n_parts", cfg->part_mask);
   if (!cfg->indptr || (!cfg->indices && cfg->num_edges > 0)) return fail(CSL_E_INVALID, "graph arrays missing");
   // the reference keeps ids in `int` (bipartite.h:55): node ids are only defined below 2^31.  Row offsets:

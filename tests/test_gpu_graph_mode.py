@@ -72,6 +72,28 @@ def check_graph_invariants(d, indptr, indices, P):
         assert sum(int(bp["owned_degree"].sum()) for bp in parts) == edges
 
 
+def check_transposed(d):
+    """FLAG_TRANSPOSE: t_indptr / t_indices of every layer but the deepest are the slice CSR + self lists sorted by
+    source (cslicer_hip.h, CSL_T_INDPTR): per in node ~r of its self entry, then the out rows of its edges ascending."""
+    L = len(d["layers"])
+    for l, parts in enumerate(d["layers"]):
+        for g, bp in enumerate(parts):
+            tag = "layer %d part %d " % (l, g)
+            if l == L - 1:
+                assert len(bp["t_indptr"]) == 0 and len(bp["t_indices"]) == 0, tag
+                continue
+            n_in = len(bp["in_nodes"])
+            if len(bp["out_nodes"]) == 0 and n_in == 0 and len(bp["t_indptr"]) == 0:
+                continue   # an empty layer has no row pointers at all (like indptr)
+            rows = np.repeat(np.arange(len(bp["out_nodes"]), dtype=np.int64), np.diff(bp["indptr"]))
+            u = np.concatenate([bp["indices"].astype(np.int64), bp["self_ids_in"].astype(np.int64)])
+            val = np.concatenate([rows, ~bp["self_ids_out"].astype(np.int64)])
+            order = np.lexsort((val, u))
+            want_ptr = np.concatenate([[0], np.cumsum(np.bincount(u, minlength=n_in))])
+            np.testing.assert_array_equal(bp["t_indptr"], want_ptr, err_msg=tag + "t_indptr")
+            np.testing.assert_array_equal(bp["t_indices"], val[order], err_msg=tag + "t_indices")
+
+
 CONFIGS = [
     (3000, 20.0, 4, (10, 10, 10), 64, 2),
     (5000, 6.0, 1, (15, 10, 5), 100, 1),
@@ -87,7 +109,9 @@ def test_graph_mode_matches_specification(abi, orc, cfg):
     n, deg, P, fan, B, S = cfg
     indptr, indices = l0.synth_graph(n, deg, seed=n + P)
     perm = np.random.default_rng(3).permutation(n)
-    e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, mode=abi.MODE_GRAPH)
+    # (with the slices by source: they must not disturb the lists of the specification)
+    e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, mode=abi.MODE_GRAPH,
+                   flags=abi.FLAG_TRANSPOSE)
     e.set_nodes(perm)
     oracles = [orc.Oracle(indptr, indices, n_parts=P, fanouts=fan) for _ in range(S)]
     for r in range(2):
@@ -98,8 +122,20 @@ def test_graph_mode_matches_specification(abi, orc, cfg):
             got = e.graph_dict(s)
             assert_same_graph(got, want, what="round %d stream %d" % (r, s))
             assert got["draws_total"] == want["draws_total"]
-            if P > 1 or True:
-                check_graph_invariants(got, indptr, indices, P)
+            check_graph_invariants(got, indptr, indices, P)
+            check_transposed(got)
+    e.close()
+
+
+def test_transpose_flag_needs_graph_mode_and_is_off_by_default(abi):
+    from cslicer import l0
+    indptr, indices = l0.synth_graph(500, 8.0, seed=1)
+    with pytest.raises(abi.CslError):
+        abi.Engine(indptr, indices, max_batch=16, flags=abi.FLAG_TRANSPOSE)     # strict mode: nothing to transpose
+    e = abi.Engine(indptr, indices, max_batch=16, mode=abi.MODE_GRAPH)
+    e.submit_seeds([np.arange(16)])
+    d = e.graph_dict(0)
+    assert all(len(bp["t_indptr"]) == 0 and len(bp["t_indices"]) == 0 for parts in d["layers"] for bp in parts)
     e.close()
 
 
