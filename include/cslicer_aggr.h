@@ -116,6 +116,19 @@ int csl_sage_cat_rows_bwd_f32(const int32_t* self_ids, const int32_t* owned, con
                               const float* gcat, int64_t ldg, float* gx, int64_t n_x, float* gagg, int64_t n_agg,
                               int32_t H, void* stream);
 
+/* Backward of csl_sage_cat_f32 (CSR form) as a gather over the slice by source (cslicer_hip.h CSL_T_INDPTR /
+ * CSL_T_INDICES, engine flag CSL_FLAG_TRANSPOSE), with the ReLU mask of the layer below, the row padding of its GEMM
+ * operand and its bias column sums in the same pass:
+ *   out[u, :] = mask_u .* sum over t in t_indices[t_indptr[u] .. t_indptr[u+1]) of
+ *               ( t < 0 ? gcat[~t, 0:H) : gcat[t, H:2H) / max(indptr[t+1] - indptr[t], 1) ),   mask_u = y ? y[u, :] > 0 : 1
+ * for u < n_src, zero rows up to n_pad; colsum[c] = sum_u out[u, c].  No atomics, nothing to pre-zero, deterministic.
+ * indptr: the slice's CSR row pointers (the forward's mean divisors).  H % 4 == 0.
+ * scratch: csl_sage_cat_bwd_t_scratch(n_pad, H) floats. */
+int64_t csl_sage_cat_bwd_t_scratch(int64_t n_pad, int32_t H);
+int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, const int32_t* indptr, const float* gcat,
+                           int64_t ldg, const float* y, int64_t ldy, int64_t n_src, int64_t n_pad, float* out,
+                           int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream);
+
 /* out[r, :] = (y == NULL || y[r, :] > 0) ? g[r, :] : 0 for r < n, zero rows for n <= r < n_pad;
  * colsum[c] = sum_r out[r, c]: ReLU backward + row padding of the GEMM operand + bias gradient in one pass
  * (two-stage reduction, no atomics, nothing to pre-zero).  scratch: csl_relu_bwd_colsum_scratch(n_pad, H) floats. */

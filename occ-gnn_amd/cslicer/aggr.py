@@ -16,7 +16,8 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_sage_cat_f32", "csl_sage_cat_bwd_f32", "csl_relu_bwd_colsum_f32", "csl_softmax_ce_f32",
            "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch", "csl_adam_f32",
            "csl_scatter_add_rows_atomic_f32", "csl_gat_logits_fwd_f32", "csl_gat_logits_bwd_f32",
-           "csl_gat_logits_bwd_scratch", "csl_spmm_sum_compact_f32", "csl_sage_cat_rows_bwd_f32"]
+           "csl_gat_logits_bwd_scratch", "csl_spmm_sum_compact_f32", "csl_sage_cat_rows_bwd_f32",
+           "csl_sage_cat_bwd_t_f32", "csl_sage_cat_bwd_t_scratch"]
 _ready = False
 
 
@@ -49,6 +50,9 @@ def _lib():
         L.csl_softmax_ce_scratch.argtypes = [i64]
         L.csl_softmax_ce_scratch.restype = i64
         L.csl_adam_f32.argtypes = [i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, i64, vp]
+        L.csl_sage_cat_bwd_t_f32.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, i64, vp, i64, vp, vp, i32, vp]
+        L.csl_sage_cat_bwd_t_scratch.argtypes = [i64, i32]
+        L.csl_sage_cat_bwd_t_scratch.restype = i64
         _ready = True
     return L
 
@@ -224,6 +228,22 @@ def relu_bwd_colsum(g, y, n, n_pad):
                                    y.stride(0) if y is not None else 0, n, n_pad, _p(out), out.stride(0),
                                    C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr() + 4 * H), H, _stream()),
          "csl_relu_bwd_colsum_f32")
+    return out, buf[:H]
+
+
+def sage_cat_bwd_t(t_indptr, t_indices, indptr, gcat, y, n_src, n_pad):
+    """Gradient of sage_cat's CSR form w.r.t. x as a gather over the slice by source (engine flag FLAG_TRANSPOSE),
+    masked by y > 0 (y None: unmasked), rows padded with zeros to n_pad; returns (out [n_pad, H], column sums [H])."""
+    gcat = _f32(gcat)
+    H = gcat.shape[1] // 2
+    out = torch.empty((n_pad, H), dtype=torch.float32, device=gcat.device)
+    L = _lib()
+    buf = torch.empty((H + max(int(L.csl_sage_cat_bwd_t_scratch(n_pad, H)), 1),), dtype=torch.float32,
+                      device=gcat.device)
+    _chk(L.csl_sage_cat_bwd_t_f32(_p(_i32(t_indptr)), _p(_i32(t_indices)), _p(_i32(indptr)), _p(gcat), gcat.stride(0),
+                                  _p(y) if y is not None else C.c_void_p(0), y.stride(0) if y is not None else 0,
+                                  n_src, n_pad, _p(out), out.stride(0), C.c_void_p(buf.data_ptr()),
+                                  C.c_void_p(buf.data_ptr() + 4 * H), H, _stream()), "csl_sage_cat_bwd_t_f32")
     return out, buf[:H]
 
 

@@ -229,6 +229,52 @@ class _SageLayerLocal(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None, None
 
 
+class _SageModelLocal(torch.autograd.Function):
+    """The WHOLE GraphSAGE model of a single part (one GPU holding every node) as one autograd node, so that the
+    backward can fuse across layers: the input gradient of layer k is GATHERED over the slice by source the slicer
+    emits (FLAG_TRANSPOSE; csl_sage_cat_bwd_t_f32: no atomics, no zero fill, deterministic) and in the same pass
+    receives the ReLU mask of layer k-1, the row padding of its GEMM operand and its bias column sums.  Per layer:
+    forward = csl_sage_cat_f32 + one GEMM (bias/ReLU epilogue); backward = weight-gradient GEMM (+ input-gradient
+    GEMM and the fused gather for k > 0).  The deepest layer reads the resident feature table through its slice's
+    in_nodes.  Arguments: feat table, n_layers, then per layer (weight, bias, Slice) in model order (deepest first)."""
+
+    @staticmethod
+    def forward(ctx, feat, n_layers, *args):
+        ws, bs, sls = args[0::3], args[1::3], args[2::3]
+        x, rowmap = feat, sls[0].in_nodes
+        cats, ys = [], []
+        for k in range(n_layers):
+            sl = sls[k]
+            m, mp = sl.n_out, _pad_rows(sl.n_out)
+            cat = aggr.sage_cat(x, sl.self_ids_in, m, mp, indptr=sl.indptr, indices=sl.indices, rowmap=rowmap)
+            y = _linear_act(bs[k], cat, ws[k], k + 1 < n_layers)
+            cats.append(cat)
+            ys.append(y)
+            x, rowmap = y[:m], None
+        ctx.n_layers, ctx.sls = n_layers, sls
+        ctx.save_for_backward(*ws, *cats, *ys)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        L, sls = ctx.n_layers, ctx.sls
+        t = ctx.saved_tensors
+        ws, cats, ys = t[:L], t[L:2 * L], t[2 * L:]
+        grads = [None] * (3 * L)
+        top = sls[L - 1]
+        gyp, gb = aggr.relu_bwd_colsum(g, None, top.n_out, cats[L - 1].shape[0])   # padding + bias sums (no mask)
+        for k in range(L - 1, -1, -1):
+            grads[3 * k] = _weight_grad(gyp, cats[k])
+            grads[3 * k + 1] = gb
+            if k == 0:
+                break
+            sl = sls[k]
+            # gradient w.r.t. layer k-1's pre-activation output, padded like its GEMM operand, and its bias sums
+            gyp, gb = aggr.sage_cat_bwd_t(sl.t_indptr, sl.t_indices, sl.indptr, gyp @ ws[k], ys[k - 1], sl.n_in,
+                                          cats[k - 1].shape[0])
+        return (None, None) + tuple(grads)
+
+
 class DistSageConv(nn.Module):
     """dist_sageconv.py:8-84: concat(self, aggregated neighbours) -> Linear(2*in, out)."""
 
@@ -317,6 +363,12 @@ class DistSAGEModel(nn.Module):
         """A single part holding every node (one GPU): each layer is one `_SageLayerLocal` node.  `feat_table` is
         the resident [N, F] feature matrix; the deepest layer indexes it through its slice's in_nodes."""
         L = len(slices)
+        if all(slices[l][part].t_indptr.numel() for l in range(L - 1)) and L > 1:
+            # the engine emitted the slices by source: one node for the model, gathered input gradients
+            args = []
+            for k, conv in enumerate(self.convs):
+                args += [conv.fc.weight, conv.fc.bias, slices[L - 1 - k][part]]
+            return _SageModelLocal.apply(feat_table, L, *args)
         x, rowmap = feat_table, slices[L - 1][part].in_nodes
         for k, conv in enumerate(self.convs):
             x = conv.layer_local(slices[L - 1 - k][part], x, k + 1 < len(self.convs), rowmap)

@@ -46,10 +46,16 @@ class Trainer(object):
             workload = np.ascontiguousarray(workload, dtype=np.int32)
             if workload.shape != (N,) or workload.min() < 0 or workload.max() >= world:
                 raise ValueError("workload must be int32 [num_nodes] with values in [0, world)")
-        # one process per part: only this rank's slices are materialised (the sampling itself is replicated)
+        # one process per part: only this rank's slices are materialised (the sampling itself is replicated).
+        # One GPU holding every node (the fused GraphSAGE path): the engine also emits the slices by source, over
+        # which the backward gathers its input gradients (CSLICER_NO_TRANSPOSE=1: atomic scatter instead, A/B switch).
+        import os
+        by_source = (not self.rank_path and self.P == 1 and model == "sage" and len(fanouts) > 1
+                     and not os.environ.get("CSLICER_NO_TRANSPOSE"))
         self.eng = _abi.Engine(indptr, indices, n_parts=self.P, fanouts=fanouts, max_batch=batch,
                                n_streams=streams, n_slots=2, device=device, mode=_abi.MODE_GRAPH,
-                               workload=workload, part_mask=(1 << rank) if self.rank_path else 0)
+                               workload=workload, part_mask=(1 << rank) if self.rank_path else 0,
+                               flags=_abi.FLAG_TRANSPOSE if by_source else 0)
         if workload is None:
             own = np.arange(rank, N, self.P, dtype=np.int64)           # owner v % P holds v at local row v // P
         else:

@@ -536,6 +536,77 @@ __global__ __launch_bounds__(BLK) void k_colsum_finish(const float* __restrict__
   if (q == 0 && c < H) out[c] = s_q[threadIdx.x] + s_q[threadIdx.x + 64] + s_q[threadIdx.x + 128] + s_q[threadIdx.x + 192];
 }
 
+// k_sage_cat_bwd_t: the backward of k_sage_cat's CSR form as a GATHER over the slice by source the slicer emits
+// (CSL_FLAG_TRANSPOSE: cslicer_hip.h, CSL_T_INDPTR).  k_sage_cat_bwd scatters with fp32 atomics into a zeroed buffer
+// (middle layer of the headline model: 84 MB of zero fill + 100 MB of L2 atomics, then k_relu_bwd_colsum reads and
+// rewrites all of it); here every source-gradient row is written exactly once, so the ReLU mask of the layer below,
+// the row padding of its GEMM operand and its bias column sums ride on the same pass:
+//   out[u, :] = mask_u .* sum_j ( t < 0 ? gcat[~t, 0:H) : gcat[t, H:2H) / max(deg_t, 1) ),  t = trow[j], j over u's list;
+//   deg_t = indptr[t+1] - indptr[t] (the forward's mean divisor);  mask_u = y ? y[u, :] > 0 : 1;
+// rows [n_src, n_pad) zero; per-block column sums to `partial` (k_colsum_finish).  The order of a list is fixed by the
+// slicer (sorted), so the result is deterministic, unlike the atomic scatter's.
+constexpr int TB_G = 16;  // lanes per source row: 16 rows in flight per block, four float4 columns per lane at H = 256
+__global__ __launch_bounds__(BLK) void k_sage_cat_bwd_t(const int* __restrict__ tptr, const int* __restrict__ trow,
+                                                        const int* __restrict__ indptr, const float* __restrict__ gcat,
+                                                        long long ldg, const float* __restrict__ y, long long ldy,
+                                                        long long n_src, long long n_pad, float* __restrict__ out,
+                                                        long long ldo, float* __restrict__ partial, int H,
+                                                        long long rows_per_block) {
+  constexpr int G = TB_G, RPB = BLK / G;
+  const int lane = threadIdx.x % G, sub = threadIdx.x / G;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r_end = r0 + rows_per_block < n_pad ? r0 + rows_per_block : n_pad;
+  __shared__ float s_sum[BLK * 4];
+  for (int c0 = 0; c0 < H; c0 += G * 4) {  // block-uniform
+    const int c = c0 + lane * 4;
+    float4 colacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long u = r0 + sub; u < r_end; u += RPB) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u < n_src && c < H) {
+        const int j0 = tptr[u], j1 = tptr[u + 1];
+        float4 a = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (y) a = *reinterpret_cast<const float4*>(y + u * ldy + c);
+        int j = j0;
+        for (; j + 2 <= j1; j += 2) {  // two contributions in flight
+          const int ta = trow[j], tb = trow[j + 1];
+          const int ra = ta < 0 ? ~ta : ta, rb = tb < 0 ? ~tb : tb;
+          // (a self entry's divisor load is issued too and ignored: no branch between the loads)
+          const int da = indptr[ra + 1] - indptr[ra], db = indptr[rb + 1] - indptr[rb];
+          const float4 va = *reinterpret_cast<const float4*>(gcat + (long long)ra * ldg + (ta < 0 ? 0 : H) + c);
+          const float4 vb = *reinterpret_cast<const float4*>(gcat + (long long)rb * ldg + (tb < 0 ? 0 : H) + c);
+          const float wa = ta < 0 ? 1.f : 1.f / (float)(da > 1 ? da : 1);
+          const float wb = tb < 0 ? 1.f : 1.f / (float)(db > 1 ? db : 1);
+          acc.x += wa * va.x, acc.y += wa * va.y, acc.z += wa * va.z, acc.w += wa * va.w;
+          acc.x += wb * vb.x, acc.y += wb * vb.y, acc.z += wb * vb.z, acc.w += wb * vb.w;
+        }
+        if (j < j1) {
+          const int ta = trow[j];
+          const int ra = ta < 0 ? ~ta : ta;
+          const int da = indptr[ra + 1] - indptr[ra];
+          const float4 va = *reinterpret_cast<const float4*>(gcat + (long long)ra * ldg + (ta < 0 ? 0 : H) + c);
+          const float wa = ta < 0 ? 1.f : 1.f / (float)(da > 1 ? da : 1);
+          acc.x += wa * va.x, acc.y += wa * va.y, acc.z += wa * va.z, acc.w += wa * va.w;
+        }
+        acc.x = a.x > 0.f ? acc.x : 0.f, acc.y = a.y > 0.f ? acc.y : 0.f, acc.z = a.z > 0.f ? acc.z : 0.f, acc.w = a.w > 0.f ? acc.w : 0.f;
+        add4(colacc, acc);
+      }
+      if (c < H) *reinterpret_cast<float4*>(out + u * ldo + c) = acc;
+    }
+    __syncthreads();
+    reinterpret_cast<float4*>(s_sum)[threadIdx.x] = colacc;
+    __syncthreads();
+    if (sub == 0 && c < H) {
+      for (int k = 1; k < RPB; k++) add4(colacc, reinterpret_cast<float4*>(s_sum)[k * G + lane]);
+      *reinterpret_cast<float4*>(partial + (long long)blockIdx.x * H + c) = colacc;
+    }
+  }
+}
+__host__ __device__ inline long long tb_rows(long long n_pad) {
+  long long r = 64;
+  while ((n_pad + r - 1) / r > 2048) r *= 2;
+  return r;
+}
+
 // k_softmax_ce: cross-entropy of one minibatch (train.py:86 loss_fn) forward AND backward in one pass:
 //   loss = -scale * sum_r log softmax(logits[r])[label_r],   grad[r, :] = scale * (softmax(logits[r]) - onehot(label_r))
 // label_r = labels[rowmap ? rowmap[ids[r]] : ids[r]] (ids = the seeds' node ids).  One wave per row (C <= 4096); a
@@ -846,6 +917,31 @@ int csl_sage_cat_bwd_f32(const int32_t* indptr, const int32_t* indices, const in
 int64_t csl_relu_bwd_colsum_scratch(int64_t n_pad, int32_t H) {
   const long long rpb = rb_rows(n_pad);
   return ((n_pad + rpb - 1) / rpb) * (int64_t)(H > 0 ? H : 0);
+}
+
+int64_t csl_sage_cat_bwd_t_scratch(int64_t n_pad, int32_t H) {
+  const long long rpb = tb_rows(n_pad);
+  return ((n_pad + rpb - 1) / rpb) * (int64_t)(H > 0 ? H : 0);
+}
+
+int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, const int32_t* indptr, const float* gcat,
+                           int64_t ldg, const float* y, int64_t ldy, int64_t n_src, int64_t n_pad, float* out,
+                           int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream) {
+  if (n_src < 0 || n_pad < n_src || H < 4 || H % 4 != 0 || !colsum) return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const long long rpb = tb_rows(n_pad);
+  const long long blocks = (n_pad + rpb - 1) / rpb;
+  if (blocks > 0) {
+    if (!out || !scratch || ldo < H || ldo % 4 != 0 || !aligned16(out)) return CSL_E_INVALID;
+    if (n_src > 0 && (!t_indptr || !t_indices || !indptr || !gcat || ldg < 2 * (int64_t)H || ldg % 4 != 0 || !aligned16(gcat)))
+      return CSL_E_INVALID;
+    if (y && (ldy < H || ldy % 4 != 0 || !aligned16(y))) return CSL_E_INVALID;
+    hipLaunchKernelGGL(k_sage_cat_bwd_t, dim3((unsigned)blocks), dim3(BLK), 0, st, t_indptr, t_indices, indptr, gcat,
+                       (long long)ldg, y, (long long)ldy, (long long)n_src, (long long)n_pad, out, (long long)ldo, scratch,
+                       (int)H, rpb);
+  }
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((H + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, (int)H, colsum);
+  return done();
 }
 
 int csl_relu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t n, int64_t n_pad,

@@ -29,13 +29,22 @@ if len(sys.argv) > 2 and sys.argv[2] == "rank":
     os.environ.setdefault("MASTER_PORT", "29578")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-t = Trainer(indptr, indices, feats, labels, 47, fanouts=(15, 10, 5), batch=1024, streams=8, hidden=256,
+from cslicer.train import use_tuned_gemms  # noqa: E402
+use_tuned_gemms()
+t = Trainer(indptr, indices, feats, labels, 47, fanouts=(15, 10, 5), batch=1024, streams=32, hidden=256,
             rank_path=dist is not None, dist=dist)
 t.set_nodes(np.random.default_rng(1).permutation(n))
-t.run(16)
+t.run(64)
+import time  # noqa: E402
+import torch  # noqa: E402
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+t.run(steps, first_batch=64)
+print('un-profiled: %.3f ms/step' % ((time.perf_counter() - t0) / steps * 1e3))
 pr = cProfile.Profile()
 pr.enable()
-t.run(steps, first_batch=16)
+t.run(steps, first_batch=64 + steps)
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(32)
+print("profiled: %.3f ms/step (host only; includes cProfile overhead)" % (st.total_tt / steps * 1e3))
+st.sort_stats("tottime").print_stats(40)

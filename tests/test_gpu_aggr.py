@@ -333,17 +333,22 @@ def test_softmax_ce_matches_torch(mods, C_, use_map):
     torch.testing.assert_close(logits.grad, ref_in.grad, rtol=1e-5, atol=1e-7)
 
 
-def test_fused_local_model_reads_the_feature_table(mods):
-    """DistSAGEModel.forward_local (every layer one fused node, the deepest one indexing the resident feature table
-    through the slice's in_nodes) == forward_parts on the gathered features, forward and weight gradients."""
+@pytest.mark.parametrize("by_source", [False, True])
+def test_fused_local_model_reads_the_feature_table(mods, by_source):
+    """DistSAGEModel.forward_local (the deepest layer indexing the resident feature table through the slice's
+    in_nodes) == forward_parts on the gathered features, forward and weight gradients.  by_source: the engine emits
+    the slices by source (FLAG_TRANSPOSE) and the model is ONE autograd node whose input gradients are gathered
+    (csl_sage_cat_bwd_t_f32); otherwise one node per layer with the atomic scatter."""
     abi, aggr, sg = mods
     from cslicer import l0
     torch.manual_seed(1)
     n, F0, hidden, classes, B = 4000, 24, 32, 5, 128
     indptr, indices = l0.synth_graph(n, 15.0, seed=9)
-    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(6, 5, 4), max_batch=B, mode=abi.MODE_GRAPH)
+    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(6, 5, 4), max_batch=B, mode=abi.MODE_GRAPH,
+                     flags=abi.FLAG_TRANSPOSE if by_source else 0)
     eng.submit_seeds([np.random.default_rng(3).permutation(n)[:B]])
     slices = sg.slices_of(eng)
+    assert bool(slices[0][0].t_indptr.numel()) == by_source and slices[2][0].t_indptr.numel() == 0
     feats = torch.randn(n, F0, device="cuda")
     model = sg.DistSAGEModel(F0, hidden, classes, n_layers=3).cuda()
     w = torch.randn(B, classes, device="cuda")
@@ -352,6 +357,7 @@ def test_fused_local_model_reads_the_feature_table(mods):
         model.zero_grad()
         if local:
             out = model.forward_local(slices, feats)
+            assert (type(out.grad_fn).__name__ == "_SageModelLocalBackward") == by_source
         else:
             out = model.forward_parts(slices, {0: feats[slices[2][0].in_nodes.long()]})[0]
         (out * w).sum().backward()
@@ -359,6 +365,45 @@ def test_fused_local_model_reads_the_feature_table(mods):
     torch.testing.assert_close(grads[0][0], grads[1][0], **TOL)
     for a_, b_ in zip(grads[0][1], grads[1][1]):
         torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-5)
+    eng.close()
+
+
+@pytest.mark.parametrize("H,masked", [(256, True), (32, False), (100, True)])
+def test_sage_cat_bwd_by_source_matches_atomic_scatter(mods, H, masked):
+    """csl_sage_cat_bwd_t_f32 over the engine's slice by source == csl_sage_cat_bwd_f32 (atomics) followed by
+    csl_relu_bwd_colsum_f32, and == a float64 dense reference."""
+    abi, aggr, sg = mods
+    from cslicer import l0
+    torch.manual_seed(H)
+    n, B = 6000, 256
+    indptr, indices = l0.synth_graph(n, 20.0, seed=2)
+    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(8, 6), max_batch=B, mode=abi.MODE_GRAPH,
+                     flags=abi.FLAG_TRANSPOSE)
+    eng.submit_seeds([np.random.default_rng(5).permutation(n)[:B]])
+    sl = sg.slices_of(eng)[0][0]
+    n_pad = sl.n_in + 37
+    gcat = torch.randn(sl.n_out, 2 * H, device="cuda")
+    y = torch.randn(n_pad, H, device="cuda") if masked else None
+    out, cs = aggr.sage_cat_bwd_t(sl.t_indptr, sl.t_indices, sl.indptr, gcat, y, sl.n_in, n_pad)
+    gx = aggr.sage_cat_bwd(sl.indptr, sl.indices, sl.self_ids_in, gcat, sl.n_out, sl.n_in)
+    want, wcs = aggr.relu_bwd_colsum(gx, y, sl.n_in, n_pad)
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(cs, wcs, rtol=1e-4, atol=1e-3)
+    # float64 reference
+    ip = sl.indptr.long().cpu().numpy()
+    deg = np.maximum(np.diff(ip), 1)
+    rows = np.repeat(np.arange(sl.n_out), np.diff(ip))
+    ref = torch.zeros(n_pad, H, dtype=torch.float64, device="cuda")
+    g64 = gcat.double()
+    ref.index_add_(0, sl.indices.long(), g64[torch.from_numpy(rows).cuda(), H:] /
+                   torch.from_numpy(deg[rows]).cuda()[:, None].double())
+    ref.index_add_(0, sl.self_ids_in.long(), g64[:, :H])
+    if masked:
+        ref = ref * (y > 0)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-5)
+    assert float(out[sl.n_in:].abs().sum()) == 0.0
+    out2, _ = aggr.sage_cat_bwd_t(sl.t_indptr, sl.t_indices, sl.indptr, gcat, y, sl.n_in, n_pad)
+    assert torch.equal(out, out2)   # deterministic: every list has a fixed order
     eng.close()
 
 
