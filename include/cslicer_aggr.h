@@ -152,6 +152,23 @@ int csl_adam_f32(int32_t count, float* const* params, const float* const* grads,
                  float* const* exp_avg_sq, const int64_t* numel, float lr, float beta1, float beta2, float eps,
                  int64_t step, void* stream);
 
+/* ---- the step's plain GEMMs (Linear forward / input gradient / weight gradient, dist_sageconv.py:34,80) ----
+ * Row-major fp32:  C[b] (m x n, ldc) = op(A[b]) (m x k) . op(B[b]) (k x n)  (+ bias[n] added to every row) (ReLU),
+ * b < batch, consecutive matrices stride_* elements apart (ignored for batch == 1); op(X) = X or X^T (trans* != 0:
+ * X is stored [k, m] resp. [n, k]).  A direct hipBLASLt call with a cached plan per shape; the algorithm of a shape
+ * is chosen by timing the library's candidates on its first use (C is overwritten several times then; environment
+ * CSLICER_GEMM_TUNE=0 takes the library's first suggestion, CSLICER_GEMM_LOG=1 reports each choice).  The library
+ * is bound at run time (the libhipblaslt.so.1 already in the process, else ROCm's).  csl_gemm_last_error: details
+ * of the last failure. */
+int csl_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k, const float* A, int64_t lda,
+                 int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b, float* C, int64_t ldc, int64_t stride_c,
+                 int32_t batch, const float* bias, int32_t relu, void* stream);
+const char* csl_gemm_last_error(void);
+
+/* out[c] = sum over b < n_slabs of slabs[b * n + c], c < n (n % 4 == 0, 16-byte aligned): the reduction of a weight
+ * gradient computed as n_slabs independent row slabs (a batched csl_gemm_f32 with transa) */
+int csl_sum_slabs_f32(const float* slabs, int64_t n, int32_t n_slabs, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

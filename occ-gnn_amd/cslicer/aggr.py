@@ -17,7 +17,8 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_relu_bwd_colsum_scratch", "csl_softmax_ce_scratch", "csl_adam_f32",
            "csl_scatter_add_rows_atomic_f32", "csl_gat_logits_fwd_f32", "csl_gat_logits_bwd_f32",
            "csl_gat_logits_bwd_scratch", "csl_spmm_sum_compact_f32", "csl_sage_cat_rows_bwd_f32",
-           "csl_sage_cat_bwd_t_f32", "csl_sage_cat_bwd_t_scratch"]
+           "csl_sage_cat_bwd_t_f32", "csl_sage_cat_bwd_t_scratch", "csl_gemm_f32", "csl_gemm_last_error",
+           "csl_sum_slabs_f32"]
 _ready = False
 
 
@@ -53,6 +54,9 @@ def _lib():
         L.csl_sage_cat_bwd_t_f32.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, i64, vp, i64, vp, vp, i32, vp]
         L.csl_sage_cat_bwd_t_scratch.argtypes = [i64, i32]
         L.csl_sage_cat_bwd_t_scratch.restype = i64
+        L.csl_gemm_f32.argtypes = [i32, i32, i64, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, vp, i32, vp]
+        L.csl_gemm_last_error.restype = C.c_char_p
+        L.csl_sum_slabs_f32.argtypes = [vp, i64, i32, vp, vp]
         _ready = True
     return L
 
@@ -229,6 +233,41 @@ def relu_bwd_colsum(g, y, n, n_pad):
                                    C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr() + 4 * H), H, _stream()),
          "csl_relu_bwd_colsum_f32")
     return out, buf[:H]
+
+
+def gemm(a, b, transa=False, transb=False, bias=None, relu=False):
+    """op(a) @ op(b) (+ bias over the columns) (ReLU) for row-major fp32 matrices (rows may be strided), as one
+    direct hipBLASLt call with a cached, timed plan per shape (csl_gemm_f32): ~5 us of host time per GEMM."""
+    m, k = (a.shape[1], a.shape[0]) if transa else (a.shape[0], a.shape[1])
+    n = b.shape[0] if transb else b.shape[1]
+    if (b.shape[1] if transb else b.shape[0]) != k or a.stride(1) != 1 or b.stride(1) != 1:
+        raise ValueError("gemm: inner dimensions differ or a column stride is not 1")
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    if m and n:
+        L = _lib()
+        rc = L.csl_gemm_f32(int(transa), int(transb), m, n, k, _p(a), a.stride(0), 0, _p(b), b.stride(0), 0,
+                            _p(out), n, 0, 1, _p(bias) if bias is not None else C.c_void_p(0), int(relu), _stream())
+        if rc < 0:
+            raise _abi.CslError(rc, "csl_gemm_f32: " + L.csl_gemm_last_error().decode())
+    return out
+
+
+def weight_grad_slabs(gy, x, n_slabs):
+    """gy^T @ x for tall row-major gy [rows, out], x [rows, in] (rows % n_slabs == 0): n_slabs independent row slabs
+    as one batched GEMM, then their sum -- the 10^5-long reduction of a 256 x 200 result otherwise runs on a few
+    dozen workgroups of the chip."""
+    rows, out_f = gy.shape
+    in_f = x.shape[1]
+    rs = rows // n_slabs
+    slabs = torch.empty((n_slabs + 1, out_f, in_f), dtype=torch.float32, device=gy.device)   # [n_slabs] = the sum
+    L = _lib()
+    rc = L.csl_gemm_f32(1, 0, out_f, in_f, rs, _p(gy), gy.stride(0), rs * gy.stride(0), _p(x), x.stride(0),
+                        rs * x.stride(0), _p(slabs), in_f, out_f * in_f, n_slabs, C.c_void_p(0), 0, _stream())
+    if rc < 0:
+        raise _abi.CslError(rc, "csl_gemm_f32: " + L.csl_gemm_last_error().decode())
+    _chk(L.csl_sum_slabs_f32(_p(slabs), out_f * in_f, n_slabs, C.c_void_p(slabs[n_slabs].data_ptr()), _stream()),
+         "csl_sum_slabs_f32")
+    return slabs[n_slabs]
 
 
 def sage_cat_bwd_t(t_indptr, t_indices, indptr, gcat, y, n_src, n_pad):

@@ -171,7 +171,7 @@ class _SageFinish(torch.autograd.Function):
         gx = gagg = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             # one launch: zero fill, self rows and degree-normalised owned rows (both index lists are unique)
-            gx, gagg = aggr.sage_cat_rows_bwd(self_ids_in, owned, deg, gyp @ weight, m, ctx.n_x, ctx.n_agg,
+            gx, gagg = aggr.sage_cat_rows_bwd(self_ids_in, owned, deg, _input_grad(gyp, weight), m, ctx.n_x, ctx.n_agg,
                                               want_x=ctx.needs_input_grad[0], want_agg=ctx.needs_input_grad[1])
         return gx, gagg, gw, gb, None, None, None, None
 
@@ -180,9 +180,26 @@ def _pad_rows(m):
     return (m + ROW_PAD - 1) // ROW_PAD * ROW_PAD if m >= ROW_PAD else m
 
 
+# CSLICER_DIRECT_GEMMS=1: the fused layers call hipBLASLt directly (aggr.gemm: cached plan per shape, the library's
+# candidates timed on first use; ~5 us of host time per GEMM where torch's dispatcher + TunableOp lookup cost 25-35).
+# Measured on the headline step (profiles/r2_e2e/README.md): the 48 candidates the library's heuristic offers are 6 %
+# slower in sum than the recorded TunableOp selections (which search every solution), and a row count first seen in
+# the timed region costs 16 ms of in-line timing -- 1.50-1.55 k minibatches/s against 1.70-1.78 k with torch's GEMMs
+# on a step that is GPU-bound anyway.  Off by default; what a host without torch would use.
+_DIRECT_GEMMS = bool(_os.environ.get("CSLICER_DIRECT_GEMMS"))
+
+
+def _input_grad(gyp, weight):
+    return aggr.gemm(gyp, weight) if _DIRECT_GEMMS and gyp.is_cuda else gyp @ weight
+
+
 def _weight_grad(gyp, cat):
     """gy^T @ cat for a tall, row-padded pair: SPLIT_K batched slabs + a sum (see _SplitKLinear)."""
     mp = gyp.shape[0]
+    if _DIRECT_GEMMS and gyp.is_cuda and (cat.shape[1] * gyp.shape[1]) % 4 == 0:
+        if mp >= ROW_PAD and mp % SPLIT_K == 0:
+            return aggr.weight_grad_slabs(gyp, cat, SPLIT_K)
+        return aggr.gemm(gyp, cat, transa=True)
     if mp >= ROW_PAD and mp % SPLIT_K == 0:
         return torch.bmm(gyp.view(SPLIT_K, mp // SPLIT_K, gyp.shape[1]).transpose(1, 2),
                          cat.view(SPLIT_K, mp // SPLIT_K, cat.shape[1])).sum(0)
@@ -191,6 +208,8 @@ def _weight_grad(gyp, cat):
 
 def _linear_act(bias, cat, weight, relu):
     """cat @ W^T + b, with the ReLU in the GEMM's epilogue where the library offers it."""
+    if _DIRECT_GEMMS and cat.is_cuda:
+        return aggr.gemm(cat, weight, transb=True, bias=bias, relu=relu)
     if relu and _FUSED_EPILOGUE:
         return torch._addmm_activation(bias, cat, weight.t(), use_gelu=False)
     y = torch.addmm(bias, cat, weight.t())
@@ -225,7 +244,7 @@ class _SageLayerLocal(torch.autograd.Function):
         gw = _weight_grad(gyp, cat)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = aggr.sage_cat_bwd(indptr, indices, self_ids_in, gyp @ weight, m, ctx.n_src)
+            gx = aggr.sage_cat_bwd(indptr, indices, self_ids_in, _input_grad(gyp, weight), m, ctx.n_src)
         return gx, gw, gb, None, None, None, None, None, None, None
 
 
@@ -270,7 +289,7 @@ class _SageModelLocal(torch.autograd.Function):
                 break
             sl = sls[k]
             # gradient w.r.t. layer k-1's pre-activation output, padded like its GEMM operand, and its bias sums
-            gyp, gb = aggr.sage_cat_bwd_t(sl.t_indptr, sl.t_indices, sl.indptr, gyp @ ws[k], ys[k - 1], sl.n_in,
+            gyp, gb = aggr.sage_cat_bwd_t(sl.t_indptr, sl.t_indices, sl.indptr, _input_grad(gyp, ws[k]), ys[k - 1], sl.n_in,
                                           cats[k - 1].shape[0])
         return (None, None) + tuple(grads)
 

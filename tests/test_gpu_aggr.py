@@ -333,14 +333,15 @@ def test_softmax_ce_matches_torch(mods, C_, use_map):
     torch.testing.assert_close(logits.grad, ref_in.grad, rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("by_source", [False, True])
-def test_fused_local_model_reads_the_feature_table(mods, by_source):
+@pytest.mark.parametrize("by_source,direct_gemms", [(False, False), (True, False), (True, True)])
+def test_fused_local_model_reads_the_feature_table(mods, by_source, direct_gemms, monkeypatch):
     """DistSAGEModel.forward_local (the deepest layer indexing the resident feature table through the slice's
     in_nodes) == forward_parts on the gathered features, forward and weight gradients.  by_source: the engine emits
     the slices by source (FLAG_TRANSPOSE) and the model is ONE autograd node whose input gradients are gathered
     (csl_sage_cat_bwd_t_f32); otherwise one node per layer with the atomic scatter."""
     abi, aggr, sg = mods
     from cslicer import l0
+    monkeypatch.setattr(sg, "_DIRECT_GEMMS", direct_gemms)   # csl_gemm_f32 instead of torch's GEMMs
     torch.manual_seed(1)
     n, F0, hidden, classes, B = 4000, 24, 32, 5, 128
     indptr, indices = l0.synth_graph(n, 15.0, seed=9)
@@ -405,6 +406,49 @@ def test_sage_cat_bwd_by_source_matches_atomic_scatter(mods, H, masked):
     out2, _ = aggr.sage_cat_bwd_t(sl.t_indptr, sl.t_indices, sl.indptr, gcat, y, sl.n_in, n_pad)
     assert torch.equal(out, out2)   # deterministic: every list has a fixed order
     eng.close()
+
+
+@pytest.mark.parametrize("m,n,k,ta,tb,bias,relu", [
+    (8192, 256, 200, False, True, True, True),      # Linear forward with bias + ReLU epilogue
+    (4096, 47, 512, False, True, True, False),      # last layer: bias only
+    (8192, 512, 256, False, False, False, False),   # input gradient
+    (256, 200, 1000, True, False, False, False),    # weight gradient, un-slabbed
+    (33, 7, 5, False, False, False, True),          # odd sizes, ReLU alone
+])
+def test_direct_gemm_matches_float64(mods, m, n, k, ta, tb, bias, relu):
+    """csl_gemm_f32 (hipBLASLt, row-major wrapper, timed plan) against a float64 product: 1e-4 of the largest entry
+    (fp32 accumulation over k <= 1000 terms)."""
+    _, aggr, _ = mods
+    torch.manual_seed(m + n)
+    a = torch.randn((k, m) if ta else (m, k), device="cuda")
+    b = torch.randn((n, k) if tb else (k, n), device="cuda")
+    bv = torch.randn(n, device="cuda") if bias else None
+    for _ in range(2):   # the second call takes the cached plan
+        got = aggr.gemm(a, b, transa=ta, transb=tb, bias=bv, relu=relu)
+        want = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+        if bias:
+            want = want + bv.double()
+        if relu:
+            want = want.relu()
+        assert got.shape == (m, n)
+        assert float((got.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    # strided rows: a column block of a wider matrix as the left operand
+    if not ta:
+        wide = torch.randn(m, k + 8, device="cuda")
+        got = aggr.gemm(wide[:, 4:4 + k], b, transb=tb)
+        want = wide[:, 4:4 + k].double() @ (b.double().t() if tb else b.double())
+        assert float((got.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+def test_weight_grad_slabs_matches_float64(mods):
+    _, aggr, _ = mods
+    torch.manual_seed(3)
+    rows, out_f, in_f = 32 * 640, 256, 200
+    gy, x = torch.randn(rows, out_f, device="cuda"), torch.randn(rows, in_f, device="cuda")
+    got = aggr.weight_grad_slabs(gy, x, 32)
+    want = gy.double().t() @ x.double()
+    assert got.shape == (out_f, in_f)
+    assert float((got.double() - want).abs().max()) <= 1e-4 * float(want.abs().max())
 
 
 def test_adam_matches_torch(mods):
