@@ -169,6 +169,39 @@ const char* csl_gemm_last_error(void);
  * gradient computed as n_slabs independent row slabs (a batched csl_gemm_f32 with transa) */
 int csl_sum_slabs_f32(const float* slabs, int64_t n, int32_t n_slabs, float* out, void* stream);
 
+/* ---- one training step of the GraphSAGE model on ONE part (python/train.py:56-88 on a GPU that holds every node) ----
+ * Forward, cross-entropy and backward for one minibatch as one call: the fused kernels above + csl_gemm_f32, issued
+ * from native code (a step is ~25 launches and 8 GEMMs of 5-90 us: issued one by one from an interpreter they cost more
+ * host time than the GPU needs for them).
+ *
+ * Model: n_layers x Linear(2 * dims[k] -> dims[k+1]) over [self | mean of sampled neighbours], ReLU between (DistSageConv,
+ * models/factory.py:7-56); layer k = 0 is the DEEPEST hop.  slices[k]: the engine's graph-mode slice of layer
+ * n_layers-1-k, part 0 of 1, device pointers (csl_list_device_ptr / csl_arena_info); t_indptr / t_indices
+ * (CSL_FLAG_TRANSPOSE) are needed for k >= 1.  n_in of layer k must equal n_out of layer k-1.
+ * weights[k] [dims[k+1], 2*dims[k]] row-major, biases[k] [dims[k+1]]; feat: the resident feature table [N, ldf], read
+ * through feat_rows = slices[0]'s in_nodes; seed_ids = the top slice's out_nodes (label of a seed: labels[id]).
+ * Results: *loss (device) = -scale * sum over the seeds of log softmax(logits)[label]; grads (device): the gradients of
+ * W_0, b_0, W_1, b_1, ... back to back.  Rows are padded to multiples of row_pad (0: no padding) so that GEMM shapes
+ * repeat; weight gradients of padded layers are reduced in n_slabs row slabs.  dims[0 .. n_layers-1] % 4 == 0.
+ * workspace: csl_sage_fwd_bwd_workspace(...) floats for THESE slice sizes, 16-byte aligned.
+ * csl_sage_last_error: what failed (thread-local). */
+typedef struct {
+  const int32_t* indptr;
+  const int32_t* indices;
+  const int32_t* self_ids_in;
+  const int32_t* t_indptr;
+  const int32_t* t_indices;
+  int64_t n_out;
+  int64_t n_in;
+} csl_sage_slice;
+int64_t csl_sage_fwd_bwd_workspace(int32_t n_layers, const int32_t* dims, const csl_sage_slice* slices, int64_t row_pad,
+                                   int32_t n_slabs);
+int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_slice* slices, const float* const* weights,
+                         const float* const* biases, const float* feat, int64_t ldf, const int32_t* feat_rows,
+                         const int32_t* seed_ids, const int64_t* labels, float scale, int64_t row_pad, int32_t n_slabs,
+                         float* grads, float* loss, float* workspace, int64_t workspace_floats, void* stream);
+const char* csl_sage_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

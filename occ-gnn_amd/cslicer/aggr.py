@@ -18,7 +18,7 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_scatter_add_rows_atomic_f32", "csl_gat_logits_fwd_f32", "csl_gat_logits_bwd_f32",
            "csl_gat_logits_bwd_scratch", "csl_spmm_sum_compact_f32", "csl_sage_cat_rows_bwd_f32",
            "csl_sage_cat_bwd_t_f32", "csl_sage_cat_bwd_t_scratch", "csl_gemm_f32", "csl_gemm_last_error",
-           "csl_sum_slabs_f32"]
+           "csl_sum_slabs_f32", "csl_sage_fwd_bwd_f32", "csl_sage_fwd_bwd_workspace", "csl_sage_last_error"]
 _ready = False
 
 
@@ -57,6 +57,10 @@ def _lib():
         L.csl_gemm_f32.argtypes = [i32, i32, i64, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, vp, i32, vp]
         L.csl_gemm_last_error.restype = C.c_char_p
         L.csl_sum_slabs_f32.argtypes = [vp, i64, i32, vp, vp]
+        L.csl_sage_fwd_bwd_workspace.argtypes = [i32, vp, vp, i64, i32]
+        L.csl_sage_fwd_bwd_workspace.restype = i64
+        L.csl_sage_fwd_bwd_f32.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, i64, i32, vp, vp, vp, i64, vp]
+        L.csl_sage_last_error.restype = C.c_char_p
         _ready = True
     return L
 
@@ -284,6 +288,60 @@ def sage_cat_bwd_t(t_indptr, t_indices, indptr, gcat, y, n_src, n_pad):
                                   n_src, n_pad, _p(out), out.stride(0), C.c_void_p(buf.data_ptr()),
                                   C.c_void_p(buf.data_ptr() + 4 * H), H, _stream()), "csl_sage_cat_bwd_t_f32")
     return out, buf[:H]
+
+
+class SageSlice(C.Structure):
+    """csl_sage_slice (cslicer_aggr.h)"""
+    _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("self_ids_in", C.c_void_p),
+                ("t_indptr", C.c_void_p), ("t_indices", C.c_void_p), ("n_out", C.c_int64), ("n_in", C.c_int64)]
+
+
+class SageStep(object):
+    """Forward + cross-entropy + backward of a DistSAGEModel on one part as ONE native call per minibatch
+    (csl_sage_fwd_bwd_f32): the gradients of W_0, b_0, W_1, ... land back to back in `self.grads` (what
+    aggr.Adam.step(flat_grads=...) takes), the loss in the slot the caller names.  The parameters are used in place
+    (their storage must not move: an optimizer that updates in place, as aggr.Adam does)."""
+
+    def __init__(self, model, row_pad, n_slabs):
+        ws, bs = [c.fc.weight for c in model.convs], [c.fc.bias for c in model.convs]
+        self.L = len(ws)
+        self.dims = [ws[0].shape[1] // 2] + [w.shape[0] for w in ws]
+        for k, (w, b) in enumerate(zip(ws, bs)):
+            if (w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous() or not b.is_contiguous()
+                    or w.shape[1] != 2 * self.dims[k]):
+                raise TypeError("contiguous float32 CUDA Linear(2*in, out) layers expected")
+        self._params = ws + bs                      # kept alive: the pointer tables below alias them
+        self._dims = (C.c_int32 * (self.L + 1))(*self.dims)
+        self._w = (C.c_void_p * self.L)(*[w.data_ptr() for w in ws])
+        self._b = (C.c_void_p * self.L)(*[b.data_ptr() for b in bs])
+        self._sl = (SageSlice * self.L)()
+        self.row_pad, self.n_slabs = int(row_pad), int(n_slabs)
+        n_grad = sum(w.numel() + b.numel() for w, b in zip(ws, bs))
+        self.grads = torch.empty((n_grad,), dtype=torch.float32, device=ws[0].device)
+        self._ws = None
+
+    def __call__(self, slices, feat, labels, scale, loss_out):
+        """slices: the part's `splitgnn.Slice`s in MODEL order (deepest hop first), from an engine with
+        FLAG_TRANSPOSE; feat: resident [N, F] features; labels int64 [N]; loss_out: one-element float32 tensor."""
+        A = _abi
+        for k, s in enumerate(slices):
+            c = self._sl[k]
+            c.indptr, c.indices, c.self_ids_in = s.ptr(A.INDPTR), s.ptr(A.INDICES), s.ptr(A.SELF_IDS_IN)
+            c.t_indptr, c.t_indices = (s.ptr(A.T_INDPTR), s.ptr(A.T_INDICES)) if k else (None, None)
+            c.n_out, c.n_in = s.n_out, s.n_in
+        L = _lib()
+        need = L.csl_sage_fwd_bwd_workspace(self.L, self._dims, self._sl, self.row_pad, self.n_slabs)
+        if need < 0:
+            raise _abi.CslError(need, "csl_sage_fwd_bwd_workspace: unsupported model or slices")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((int(need * 1.25) + 1024,), dtype=torch.float32, device=feat.device)
+        rc = L.csl_sage_fwd_bwd_f32(self.L, self._dims, self._sl, self._w, self._b, feat.data_ptr(), feat.stride(0),
+                                    slices[0].ptr(A.IN_NODES), slices[-1].ptr(A.OUT_NODES), labels.data_ptr(),
+                                    float(scale), self.row_pad, self.n_slabs, self.grads.data_ptr(),
+                                    loss_out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _stream())
+        if rc < 0:
+            raise _abi.CslError(rc, "csl_sage_fwd_bwd_f32: " + L.csl_sage_last_error().decode() + " / " +
+                                L.csl_gemm_last_error().decode())
 
 
 class SoftmaxCE(torch.autograd.Function):

@@ -45,12 +45,47 @@ def _view_i32(ptr, n, device):
     return torch.as_tensor(_DevArray(ptr, n), device=device)
 
 
-class Slice(object):
-    """One BiPartite of graph mode on the device: int32 tensors that alias the engine's arena."""
+_SLICE_LISTS = {"in_nodes": _abi.IN_NODES, "out_nodes": _abi.OUT_NODES, "indptr": _abi.INDPTR, "indices": _abi.INDICES,
+                "owned_out_nodes": _abi.OWNED_OUT_NODES, "self_ids_in": _abi.SELF_IDS_IN,
+                "owned_degree": _abi.OWNED_DEGREE, "from_all": _abi.FROM_IDS, "to_all": _abi.TO_IDS,
+                "t_indptr": _abi.T_INDPTR, "t_indices": _abi.T_INDICES}
 
-    __slots__ = ("part", "n_parts", "in_nodes", "out_nodes", "indptr", "indices", "owned_out_nodes",
-                 "self_ids_in", "owned_degree", "from_ids", "to_ids", "from_all", "to_all", "n_in", "n_out", "n_owned",
-                 "t_indptr", "t_indices")
+
+class Slice(object):
+    """One BiPartite of graph mode on the device: int32 tensors that alias the engine's arena.  The tensors are
+    made when first asked for (a training step touches a third of the ~13 lists x 3 layers; every view costs a
+    microsecond of host time); the sizes n_in / n_out / n_owned / n_edges come from the sample's meta.
+    t_indptr / t_indices: the slice by source (engine flag FLAG_TRANSPOSE; empty otherwise and for the deepest layer).
+    from_all / to_all: the per-peer lists back to back (receiver / sender order, the own one empty)."""
+
+    __slots__ = ("part", "n_parts", "n_in", "n_out", "n_owned", "n_edges", "_t", "_origin", "_lbase", "_lm") + \
+        tuple(_SLICE_LISTS) + ("from_ids", "to_ids")
+
+    def _seg(self, kind, lo, hi):
+        o = self._origin + self._lbase[kind]
+        return self._t[o + lo:o + hi]
+
+    def ptr(self, kind):
+        """device address of the part's list of `kind` (an _abi list kind) inside the engine's arena"""
+        return self._t.data_ptr() + 4 * (self._origin + self._lbase[kind] + int(self._lm.off[kind][self.part]))
+
+    def __getattr__(self, name):          # only reached for a list that has not been made yet
+        lm, g = self._lm, self.part
+        kind = _SLICE_LISTS.get(name)
+        if kind is not None:
+            v = self._seg(kind, int(lm.off[kind][g]), int(lm.off[kind][g + 1]))
+        elif name == "from_ids":
+            f0 = int(lm.off[_abi.FROM_IDS][g])
+            v = [self._seg(_abi.FROM_IDS, f0 + int(lm.pair_off[0][g][p]), f0 + int(lm.pair_off[0][g][p + 1]))
+                 for p in range(self.n_parts)]
+        elif name == "to_ids":
+            t0 = int(lm.off[_abi.TO_IDS][g])
+            v = [self._seg(_abi.TO_IDS, t0 + int(lm.pair_off[1][g][p]), t0 + int(lm.pair_off[1][g][p + 1]))
+                 for p in range(self.n_parts)]
+        else:
+            raise AttributeError(name)
+        object.__setattr__(self, name, v)
+        return v
 
 
 def _arena_tensors(eng, device):
@@ -85,33 +120,15 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
         t, stride, lbase = arenas[l]
         origin = (slot * eng.n_streams + stream) * stride
 
-        def seg(kind, g, lo=None, hi=None):
-            a = int(lm.off[kind][g]) if lo is None else lo
-            b = int(lm.off[kind][g + 1]) if hi is None else hi
-            o = origin + lbase[kind]
-            return t[o + a:o + b]
-
         row = {}
         for g in parts:
             s = Slice()
             s.part, s.n_parts = g, P
-            s.in_nodes = seg(_abi.IN_NODES, g)
-            s.out_nodes = seg(_abi.OUT_NODES, g)
-            s.indptr = seg(_abi.INDPTR, g)
-            s.indices = seg(_abi.INDICES, g)
-            s.owned_out_nodes = seg(_abi.OWNED_OUT_NODES, g)
-            s.self_ids_in = seg(_abi.SELF_IDS_IN, g)
-            s.owned_degree = seg(_abi.OWNED_DEGREE, g)
-            # the slice by source (engine flag FLAG_TRANSPOSE; empty otherwise and for the deepest layer)
-            s.t_indptr, s.t_indices = seg(_abi.T_INDPTR, g), seg(_abi.T_INDICES, g)
-            f0, t0 = int(lm.off[_abi.FROM_IDS][g]), int(lm.off[_abi.TO_IDS][g])
-            s.from_ids = [seg(_abi.FROM_IDS, g, f0 + int(lm.pair_off[0][g][p]), f0 + int(lm.pair_off[0][g][p + 1]))
-                          for p in range(P)]
-            s.to_ids = [seg(_abi.TO_IDS, g, t0 + int(lm.pair_off[1][g][p]), t0 + int(lm.pair_off[1][g][p + 1]))
-                        for p in range(P)]
-            # the per-peer lists are contiguous (receiver / sender order, the own one empty): all peers at once
-            s.from_all, s.to_all = seg(_abi.FROM_IDS, g), seg(_abi.TO_IDS, g)
-            s.n_in, s.n_out, s.n_owned = s.in_nodes.numel(), s.out_nodes.numel(), s.owned_out_nodes.numel()
+            s._t, s._origin, s._lbase, s._lm = t, origin, lbase, lm
+            s.n_in = int(lm.off[_abi.IN_NODES][g + 1]) - int(lm.off[_abi.IN_NODES][g])
+            s.n_out = int(lm.off[_abi.OUT_NODES][g + 1]) - int(lm.off[_abi.OUT_NODES][g])
+            s.n_owned = int(lm.off[_abi.OWNED_OUT_NODES][g + 1]) - int(lm.off[_abi.OWNED_OUT_NODES][g])
+            s.n_edges = int(lm.off[_abi.INDICES][g + 1]) - int(lm.off[_abi.INDICES][g])
             row[g] = s
         out.append(row)
     return out

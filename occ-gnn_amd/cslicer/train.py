@@ -23,6 +23,11 @@ from . import _abi, _roctx, aggr, shard, splitgnn
 
 
 class Trainer(object):
+    # result slots of the engine: round r lives in slot r % SLOTS.  Three, so that the slot the NEXT round is sliced
+    # into was last read two rounds ago: waiting for that round's end event never drains the training stream (with
+    # two slots the wait was for the steps just enqueued, an idle gap on the GPU once per round).
+    SLOTS = 3
+
     def __init__(self, indptr, indices, features, labels, n_classes, rank=0, world=1, fanouts=(15, 10, 5),
                  batch=1024, streams=8, hidden=256, lr=1e-3, device=0, dist=None, seed=0, overlap=False,
                  model="sage", heads=8, rank_path=None, workload=None, feat_dim=None):
@@ -53,7 +58,7 @@ class Trainer(object):
         by_source = (not self.rank_path and self.P == 1 and model == "sage" and len(fanouts) > 1
                      and not os.environ.get("CSLICER_NO_TRANSPOSE"))
         self.eng = _abi.Engine(indptr, indices, n_parts=self.P, fanouts=fanouts, max_batch=batch,
-                               n_streams=streams, n_slots=2, device=device, mode=_abi.MODE_GRAPH,
+                               n_streams=streams, n_slots=self.SLOTS, device=device, mode=_abi.MODE_GRAPH,
                                workload=workload, part_mask=(1 << rank) if self.rank_path else 0,
                                flags=_abi.FLAG_TRANSPOSE if by_source else 0)
         if workload is None:
@@ -88,6 +93,13 @@ class Trainer(object):
         # torch.optim.Adam's update in one HIP launch per step (the library's for-each form is eight small
         # launches, ~0.1 ms of GPU time per step; its fused form one of 42 us for these six small tensors)
         self.opt = aggr.Adam(list(self.model.parameters()), lr=lr)
+        # the fused single-GPU GraphSAGE step as one native call per minibatch (CSLICER_PY_STEP=1: the same kernels
+        # issued from Python through an autograd node, A/B switch and what the tests compare it with)
+        self.native = None
+        if (by_source and F % 4 == 0 and hidden % 4 == 0 and not os.environ.get("CSLICER_PY_STEP")
+                and not splitgnn._NO_LOCAL_FUSE):
+            self.native = aggr.SageStep(self.model, splitgnn.ROW_PAD, splitgnn.SPLIT_K)
+            self._loss_ring, self._ring_at = torch.zeros((4096,), dtype=torch.float32, device=self.dev), 0
         self.comm = splitgnn.DistComm(device=self.dev) if self.rank_path else None
         self.overlap = overlap
         self.t_forward = self.t_slice = 0.0
@@ -114,10 +126,21 @@ class Trainer(object):
             u = self.units[k]
             u["rows"] += sl.n_owned
             u["src"] += sl.n_in
-            u["edges"] += sl.indices.numel()
+            u["edges"] += sl.n_edges
         n_seeds = int(meta.n_seeds)
         fused = (not self.rank_path and self.kind == "sage" and self.P == 1 and self.feat.shape[1] % 4 == 0
                  and not splitgnn._NO_LOCAL_FUSE)
+        if self.native is not None:
+            # forward, loss, backward: one native call; the optimizer: a second one on the flat gradient buffer
+            _roctx.push("step_native")
+            loss = self._loss_ring[self._ring_at:self._ring_at + 1]    # (run() sized the ring for its steps)
+            self._ring_at += 1
+            self.native([slices[self.L - 1 - k][self.rank] for k in range(self.L)], self.feat, self.labels,
+                        1.0 / max(n_seeds, 1), loss)
+            self.opt.step(flat_grads=self.native.grads)
+            _roctx.pop()
+            self.steps_done += 1
+            return loss
         if fused:
             # one GPU holding every node: the deepest layer reads the resident feature table through the slice's
             # in_nodes (no gathered input matrix), every layer is one fused node, the loss is one HIP pass
@@ -182,16 +205,27 @@ class Trainer(object):
         if not plan:
             return losses
 
+        if self.native is not None:
+            if self._loss_ring.numel() < n_steps:
+                self._loss_ring = torch.zeros((n_steps,), dtype=torch.float32, device=self.dev)
+            self._ring_at = 0
+        done = [None] * self.SLOTS     # per slot: event behind the last step that read the slot
+
         def submit(r):
-            torch.cuda.current_stream().synchronize()     # the slot's previous consumer has finished
-            self.eng.submit_round(plan[r][0], self.B, plan[r][1], slot=r & 1)
+            ev = done[r % self.SLOTS]
+            if ev is not None:
+                ev.synchronize()                          # the slot's previous consumer has finished
+            self.eng.submit_round(plan[r][0], self.B, plan[r][1], slot=r % self.SLOTS)
 
         submit(0)
         for r in range(len(plan)):
             if r + 1 < len(plan):
                 submit(r + 1)
             for s in range(plan[r][1]):
-                losses.append(self._step(s, r & 1))
+                losses.append(self._step(s, r % self.SLOTS))
+            ev = torch.cuda.Event()
+            ev.record()
+            done[r % self.SLOTS] = ev
         torch.cuda.synchronize()
         return [float(x) for x in losses]
 

@@ -64,6 +64,9 @@ struct State {
   void* ws = nullptr;
   size_t ws_bytes = 0;
   std::map<Key, Plan> plans;
+  // the algorithm last chosen for a shape CLASS (the shape with its long dimension -- the rows of a minibatch layer:
+  // m, or k of a weight gradient -- blanked): a new row count of a known class takes it without timing anything
+  std::map<Key, std::pair<hipblasLtMatmulAlgo_t, size_t>> classes;
   char err[256] = {0};
 };
 State g;
@@ -158,6 +161,16 @@ int make_plan(const Key& key, Plan& p, const float* A, const float* B, float* C,
     LT(a.LayoutSet(p.lb, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_second, sizeof(s_second)));
     LT(a.LayoutSet(p.lc, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_c, sizeof(s_c)));
   }
+  const Key cls = transa ? Key(transa, transb, m, n, 0, lda, ldb, ldc, batch, 0, 0, sc, epi)
+                         : Key(transa, transb, 0, n, k, lda, ldb, ldc, batch, 0, sb, 0, epi);
+  {
+    auto ci = g.classes.find(cls);
+    if (ci != g.classes.end()) {
+      p.algo = ci->second.first;
+      p.ws = ci->second.second;
+      if (run(p, A, B, C, bias, st) == 0) return 0;  // (else: the library refuses it for this size -- time afresh)
+    }
+  }
   hipblasLtMatmulPreference_t pref = nullptr;
   LT(a.PrefCreate(&pref));
   const uint64_t wsb = g.ws_bytes;
@@ -216,6 +229,7 @@ int make_plan(const Key& key, Plan& p, const float* A, const float* B, float* C,
   p.algo = res[best].algo;
   p.ws = res[best].workspaceSize;
   p.us = best_us;
+  g.classes[cls] = std::make_pair(p.algo, p.ws);
   if (getenv("CSLICER_GEMM_LOG"))
     fprintf(stderr, "[csl_gemm] %c%c m=%lld n=%lld k=%lld batch=%d epilogue=%d: candidate %d of %d (%d timed), %.1f us\n",
             transa ? 'T' : 'N', transb ? 'T' : 'N', m, n, k, batch, epi, best, got, p.n_tried, best_us);

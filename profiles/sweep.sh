@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   for v in $VARIANTS; do
     name=${v%%:*}; flags=$(echo ${v#*:} | tr + ' ')
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I $R/include -w $flags \
-      -o $D/lib_$name.so $R/occ-gnn_amd/csrc/cslicer_hip.hip $R/occ-gnn_amd/csrc/aggregate.hip $R/occ-gnn_amd/csrc/gemm_lt.hip -ldl &
+      -o $D/lib_$name.so $R/occ-gnn_amd/csrc/cslicer_hip.hip $R/occ-gnn_amd/csrc/aggregate.hip $R/occ-gnn_amd/csrc/gemm_lt.hip $R/occ-gnn_amd/csrc/sage_step.hip -ldl &
   done; wait; ls $D
 else
   for v in $VARIANTS; do

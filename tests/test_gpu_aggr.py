@@ -369,6 +369,35 @@ def test_fused_local_model_reads_the_feature_table(mods, by_source, direct_gemms
     eng.close()
 
 
+@pytest.mark.parametrize("B,row_pad", [(128, 64), (128, 0), (700, 512)])
+def test_native_step_matches_the_autograd_path(mods, B, row_pad):
+    """csl_sage_fwd_bwd_f32 (forward + loss + backward as one native call, direct hipBLASLt GEMMs) against the same
+    model through torch autograd (_SageModelLocal + SoftmaxCE, torch GEMMs): loss and every parameter gradient."""
+    abi, aggr, sg = mods
+    from cslicer import l0
+    torch.manual_seed(2)
+    n, F0, hidden, classes = 5000, 24, 32, 7
+    indptr, indices = l0.synth_graph(n, 15.0, seed=B)
+    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(6, 5, 4), max_batch=B, mode=abi.MODE_GRAPH,
+                     flags=abi.FLAG_TRANSPOSE)
+    eng.submit_seeds([np.random.default_rng(3).permutation(n)[:B]])
+    slices = sg.slices_of(eng)
+    feats = torch.randn(n, F0, device="cuda")
+    labels = torch.randint(0, classes, (n,), device="cuda")
+    model = sg.DistSAGEModel(F0, hidden, classes, n_layers=3).cuda()
+    out = model.forward_local(slices, feats)
+    loss = aggr.SoftmaxCE.apply(out, slices[0][0].out_nodes, labels, 1.0 / B)
+    loss.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    step = aggr.SageStep(model, row_pad, 4)
+    got_loss = torch.zeros(1, device="cuda")
+    for _ in range(2):   # the second call reuses workspace and GEMM plans
+        step([slices[2][0], slices[1][0], slices[0][0]], feats, labels, 1.0 / B, got_loss)
+        torch.testing.assert_close(got_loss[0], loss.detach(), rtol=1e-5, atol=1e-6)
+        assert float((step.grads - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    eng.close()
+
+
 @pytest.mark.parametrize("H,masked", [(256, True), (32, False), (100, True)])
 def test_sage_cat_bwd_by_source_matches_atomic_scatter(mods, H, masked):
     """csl_sage_cat_bwd_t_f32 over the engine's slice by source == csl_sage_cat_bwd_f32 (atomics) followed by
