@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--serial-rounds", action="store_true",
                     help="no overlap of consecutive rounds (profiling: undisturbed per-kernel durations)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
-    ap.add_argument("--e2e-steps", type=int, default=64,
+    ap.add_argument("--e2e-steps", type=int, default=128,
                     help="end-to-end training minibatches for the secondary iters/s figure (0 = skip)")
     ap.add_argument("--no-e2e-multi", action="store_true", help="several GPUs: skip the split-parallel training leg")
     ap.add_argument("--e2e-timeout", type=float, default=180.0, help="several GPUs: watchdog of the e2e leg, seconds")
@@ -507,16 +507,17 @@ def main():
                      batch=B, streams=args.e2e_streams, hidden=args.e2e_hidden, device=device, dist=dist,
                      model=args.e2e_model, heads=args.e2e_heads, feat_dim=args.e2e_feat)
         tr.set_nodes(perm)
-        tr.run(16)                       # warm-up (allocator, rng window, GEMM heuristics)
+        tr.run(48)                       # warm-up: more than one engine round (allocator, rng window, GEMM plans)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tr.reset_units()
-        tr.run(args.e2e_steps, first_batch=16)
+        tr.run(args.e2e_steps, first_batch=48)
         torch.cuda.synchronize()
         barrier()
         t_e2e = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)
         work = tr.step_work(args.e2e_steps) if args.e2e_model == "sage" else None
+        tr_native = getattr(tr, "native", None) is not None
         tr.close()
         roof = None
         if work is not None:
@@ -535,7 +536,10 @@ def main():
             }
         return {
             "roofline": roof,
-            "tuned_gemm_selections": bool(tuned),
+            # one native call per minibatch (csl_sage_fwd_bwd_f32, direct hipBLASLt GEMMs timed per shape) or the
+            # kernels issued from Python through torch autograd (then with torch's GEMMs and these selections)
+            "native_step": tr_native,
+            "tuned_gemm_selections": bool(tuned) and not tr_native,
             "iters_per_sec": args.e2e_steps / t_e2e, "ms_per_iter": 1e3 * t_e2e / args.e2e_steps,
             "steps": args.e2e_steps,
             "config": "split-parallel %s fanout %s, batch %d (global), %d part(s) = %d GPU(s), features %d, "
