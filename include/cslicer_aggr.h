@@ -164,6 +164,13 @@ int csl_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k
                  int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b, float* C, int64_t ldc, int64_t stride_c,
                  int32_t batch, const float* bias, int32_t relu, void* stream);
 const char* csl_gemm_last_error(void);
+/* Recorded plans.  CSLICER_GEMM_TUNE=all times EVERY solution the library has for a shape class (what a framework's
+ * offline tuner does: ~0.3 s per class) instead of the heuristic's candidates; csl_gemm_save_plans writes the chosen
+ * solution index of every class seen so far to a text file, csl_gemm_load_plans (returns the number of entries) makes
+ * later plans of those classes take the recorded solution without timing anything.  The indices belong to one library
+ * version (named in the file's header); with another version the file is ignored. */
+int csl_gemm_save_plans(const char* path);
+int csl_gemm_load_plans(const char* path);
 
 /* out[c] = sum over b < n_slabs of slabs[b * n + c], c < n (n % 4 == 0, 16-byte aligned): the reduction of a weight
  * gradient computed as n_slabs independent row slabs (a batched csl_gemm_f32 with transa) */

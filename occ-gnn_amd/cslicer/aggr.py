@@ -6,6 +6,7 @@ Reference semantics: python/data/bipartite.py:61-99 (gather, self_gather, pull_f
 push_from_remotes), src/gnn/sage.cu:7-28, src/gnn/dist_sage.cu:193-199.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -18,7 +19,8 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_scatter_add_rows_atomic_f32", "csl_gat_logits_fwd_f32", "csl_gat_logits_bwd_f32",
            "csl_gat_logits_bwd_scratch", "csl_spmm_sum_compact_f32", "csl_sage_cat_rows_bwd_f32",
            "csl_sage_cat_bwd_t_f32", "csl_sage_cat_bwd_t_scratch", "csl_gemm_f32", "csl_gemm_last_error",
-           "csl_sum_slabs_f32", "csl_sage_fwd_bwd_f32", "csl_sage_fwd_bwd_workspace", "csl_sage_last_error"]
+           "csl_sum_slabs_f32", "csl_sage_fwd_bwd_f32", "csl_sage_fwd_bwd_workspace", "csl_sage_last_error",
+           "csl_gemm_save_plans", "csl_gemm_load_plans"]
 _ready = False
 
 
@@ -61,6 +63,8 @@ def _lib():
         L.csl_sage_fwd_bwd_workspace.restype = i64
         L.csl_sage_fwd_bwd_f32.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, i64, i32, vp, vp, vp, i64, vp]
         L.csl_sage_last_error.restype = C.c_char_p
+        L.csl_gemm_save_plans.argtypes = [C.c_char_p]
+        L.csl_gemm_load_plans.argtypes = [C.c_char_p]
         _ready = True
     return L
 
@@ -256,6 +260,26 @@ def gemm(a, b, transa=False, transb=False, bias=None, relu=False):
     return out
 
 
+GEMM_PLANS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_plans_gfx950.txt")
+
+
+def gemm_load_plans(path=None):
+    """Recorded csl_gemm_f32 plans (solution index per shape class; profiles/tune_direct_gemms.sh made the shipped
+    file with CSLICER_GEMM_TUNE=all): shapes they cover are planned without timing.  Returns the number of entries
+    (0: no file).  CSLICER_GEMM_PLANS=<file> overrides the shipped file, CSLICER_GEMM_PLANS=0 disables it."""
+    env = os.environ.get("CSLICER_GEMM_PLANS")
+    if env == "0":
+        return 0
+    path = path or env or GEMM_PLANS
+    if not os.path.exists(path):
+        return 0
+    return max(int(_lib().csl_gemm_load_plans(path.encode())), 0)
+
+
+def gemm_save_plans(path):
+    _chk(_lib().csl_gemm_save_plans(path.encode()), "csl_gemm_save_plans")
+
+
 def weight_grad_slabs(gy, x, n_slabs):
     """gy^T @ x for tall row-major gy [rows, out], x [rows, in] (rows % n_slabs == 0): n_slabs independent row slabs
     as one batched GEMM, then their sum -- the 10^5-long reduction of a 256 x 200 result otherwise runs on a few
@@ -319,6 +343,7 @@ class SageStep(object):
         n_grad = sum(w.numel() + b.numel() for w, b in zip(ws, bs))
         self.grads = torch.empty((n_grad,), dtype=torch.float32, device=ws[0].device)
         self._ws = None
+        gemm_load_plans()
 
     def __call__(self, slices, feat, labels, scale, loss_out):
         """slices: the part's `splitgnn.Slice`s in MODEL order (deepest hop first), from an engine with

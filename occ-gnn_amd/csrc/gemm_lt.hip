@@ -40,6 +40,18 @@ struct LtApi {
   decltype(&hipblasLtMatmulPreferenceDestroy) PrefDestroy = nullptr;
   decltype(&hipblasLtMatmulAlgoGetHeuristic) Heuristic = nullptr;
   decltype(&hipblasLtMatmul) Matmul = nullptr;
+  decltype(&hipblasLtGetVersion) GetVersion = nullptr;
+  // hipblaslt_ext (C++ entry points, bound by their mangled names; optional: exhaustive tuning and recorded plans)
+  hipblasStatus_t (*AllAlgos)(hipblasLtHandle_t, int /*GemmType*/, hipblasOperation_t, hipblasOperation_t, hipDataType,
+                              hipDataType, hipDataType, hipDataType, hipblasComputeType_t,
+                              std::vector<hipblasLtMatmulHeuristicResult_t>&) = nullptr;
+  hipblasStatus_t (*AlgosFromIndex)(hipblasLtHandle_t, std::vector<int>&,
+                                    std::vector<hipblasLtMatmulHeuristicResult_t>&) = nullptr;
+  hipblasStatus_t (*IsSupported)(hipblasLtHandle_t, hipblasLtMatmulDesc_t, const void*, hipblasLtMatrixLayout_t,
+                                 hipblasLtMatrixLayout_t, const void*, hipblasLtMatrixLayout_t, hipblasLtMatrixLayout_t,
+                                 hipblasLtMatmulAlgo_t&, size_t&) = nullptr;
+  int (*IndexFromAlgo)(hipblasLtMatmulAlgo_t&) = nullptr;
+  bool ext() const { return AllAlgos && AlgosFromIndex && IsSupported && IndexFromAlgo; }
 };
 
 struct Plan {
@@ -67,6 +79,9 @@ struct State {
   // the algorithm last chosen for a shape CLASS (the shape with its long dimension -- the rows of a minibatch layer:
   // m, or k of a weight gradient -- blanked): a new row count of a known class takes it without timing anything
   std::map<Key, std::pair<hipblasLtMatmulAlgo_t, size_t>> classes;
+  // recorded plans (csl_gemm_load_plans): shape class -> the library's solution index, valid for one library version
+  std::map<Key, int> recorded;
+  int recorded_version = -1;
   char err[256] = {0};
 };
 State g;
@@ -106,8 +121,19 @@ bool load_api() {
     snprintf(g.err, sizeof(g.err), "hipBLASLt lacks an entry point this file needs");
     return false;
   }
+  bind(lib, "hipblasLtGetVersion", a.GetVersion);
+  bind(lib, "_ZN13hipblaslt_ext11getAllAlgosEPvNS_8GemmTypeE18hipblasOperation_tS2_11hipDataTypeS3_S3_S3_20hipblasComputeType_tRSt6vectorI33_hipblasLtMatmulHeuristicResult_tSaIS6_EE", a.AllAlgos);
+  bind(lib, "_ZN13hipblaslt_ext17getAlgosFromIndexEPvRSt6vectorIiSaIiEERS1_I33_hipblasLtMatmulHeuristicResult_tSaIS5_EE", a.AlgosFromIndex);
+  bind(lib, "_ZN13hipblaslt_ext21matmulIsAlgoSupportedEPvP27hipblasLtMatmulDescOpaque_tPKvP29hipblasLtMatrixLayoutOpaque_tS6_S4_S6_S6_R22_hipblasLtMatmulAlgo_tRm", a.IsSupported);
+  bind(lib, "_ZN13hipblaslt_ext16getIndexFromAlgoER22_hipblasLtMatmulAlgo_t", a.IndexFromAlgo);
   a.lib = lib;
   return true;
+}
+
+int lib_version() {
+  int v = -1;
+  if (g.api.GetVersion && g.handle) g.api.GetVersion(g.handle, &v);
+  return v;
 }
 
 #define LT(x)                                                                                 \
@@ -171,6 +197,28 @@ int make_plan(const Key& key, Plan& p, const float* A, const float* B, float* C,
       if (run(p, A, B, C, bias, st) == 0) return 0;  // (else: the library refuses it for this size -- time afresh)
     }
   }
+  const float one = 1.f, zero = 0.f;
+  if (a.ext() && g.recorded_version == lib_version()) {
+    auto ri = g.recorded.find(cls);
+    if (ri != g.recorded.end()) {
+      std::vector<int> idx(1, ri->second);
+      std::vector<hipblasLtMatmulHeuristicResult_t> rr;
+      size_t wsz = 0;
+      if (a.AlgosFromIndex(g.handle, idx, rr) == HIPBLAS_STATUS_SUCCESS && !rr.empty() &&
+          a.IsSupported(g.handle, p.desc, &one, p.la, p.lb, &zero, p.lc, p.lc, rr[0].algo, wsz) == HIPBLAS_STATUS_SUCCESS &&
+          wsz <= g.ws_bytes) {
+        p.algo = rr[0].algo;
+        p.ws = wsz;
+        if (run(p, A, B, C, bias, st) == 0) {
+          g.classes[cls] = std::make_pair(p.algo, p.ws);
+          return 0;
+        }
+      }
+    }
+  }
+  const char* tune_env = getenv("CSLICER_GEMM_TUNE");
+  const bool tune = !(tune_env && tune_env[0] == '0');
+  const bool exhaustive = tune_env && tune_env[0] == 'a' && a.ext();  // "all": every solution of the library
   hipblasLtMatmulPreference_t pref = nullptr;
   LT(a.PrefCreate(&pref));
   const uint64_t wsb = g.ws_bytes;
@@ -183,8 +231,22 @@ int make_plan(const Key& key, Plan& p, const float* A, const float* B, float* C,
     snprintf(g.err, sizeof(g.err), "hipBLASLt has no algorithm for this GEMM (status %d, %d candidates)", (int)hs, got);
     return CSL_E_HIP;
   }
-  const char* tune_env = getenv("CSLICER_GEMM_TUNE");
-  const bool tune = !(tune_env && tune_env[0] == '0');
+  res.resize(got);
+  if (exhaustive) {
+    // what a framework's offline tuner does: every solution the library has for these types, filtered by support
+    std::vector<hipblasLtMatmulHeuristicResult_t> all;
+    if (a.AllAlgos(g.handle, 1 /* HIPBLASLT_GEMM */, (hipblasOperation_t)op_first, (hipblasOperation_t)op_second, HIP_R_32F,
+                   HIP_R_32F, HIP_R_32F, HIP_R_32F, HIPBLAS_COMPUTE_32F, all) == HIPBLAS_STATUS_SUCCESS) {
+      for (auto& r : all) {
+        size_t wsz = 0;
+        if (a.IsSupported(g.handle, p.desc, &one, p.la, p.lb, &zero, p.lc, p.lc, r.algo, wsz) != HIPBLAS_STATUS_SUCCESS) continue;
+        r.workspaceSize = wsz;
+        r.state = HIPBLAS_STATUS_SUCCESS;
+        res.push_back(r);
+      }
+    }
+    got = (int)res.size();
+  }
   int best = -1;
   float best_us = 0.f;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -200,8 +262,15 @@ int make_plan(const Key& key, Plan& p, const float* A, const float* B, float* C,
     }
     p.algo = res[i].algo;
     p.ws = res[i].workspaceSize;
+    HIPOK(hipEventRecord(e0, st));
     if (run(p, A, B, C, bias, st) != 0) continue;  // (a candidate the library then refuses is skipped)
+    HIPOK(hipEventRecord(e1, st));
     if (hipStreamSynchronize(st) != hipSuccess) return CSL_E_HIP;
+    if (best >= 0) {  // a first run three times slower than the best so far is not timed further
+      float ms1 = 0.f;
+      HIPOK(hipEventElapsedTime(&ms1, e0, e1));
+      if (ms1 * 1e3f > 3.f * best_us + 20.f) continue;
+    }
     const int reps = 3;
     HIPOK(hipEventRecord(e0, st));
     bool ok = true;
@@ -296,6 +365,53 @@ int csl_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k
     it = g.plans.emplace(key, p).first;
   }
   return run(it->second, A, B, C, bias, (hipStream_t)stream);
+}
+
+/* Recorded plans: one line per shape class, "ta tb m n k lda ldb ldc batch sa sb sc epilogue index" (the long dimension
+ * and the strides that follow it are 0), after a header naming the library version the solution indices belong to. */
+int csl_gemm_save_plans(const char* path) {
+  std::lock_guard<std::mutex> lock(g.mu);
+  if (!path || !g.handle || !g.api.ext()) return CSL_E_STATE;
+  FILE* f = fopen(path, "w");
+  if (!f) return CSL_E_INVALID;
+  fprintf(f, "# csl_gemm_f32 plans: hipblaslt %d\n", lib_version());
+  for (auto& kv : g.classes) {
+    int ta, tb, batch, epi;
+    long long m, n, k, lda, ldb, ldc, sa, sb, sc;
+    std::tie(ta, tb, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, epi) = kv.first;
+    hipblasLtMatmulAlgo_t algo = kv.second.first;
+    fprintf(f, "%d %d %lld %lld %lld %lld %lld %lld %d %lld %lld %lld %d %d\n", ta, tb, m, n, k, lda, ldb, ldc, batch, sa, sb,
+            sc, epi, g.api.IndexFromAlgo(algo));
+  }
+  fclose(f);
+  return 0;
+}
+
+int csl_gemm_load_plans(const char* path) {
+  std::lock_guard<std::mutex> lock(g.mu);
+  if (!path) return CSL_E_INVALID;
+  FILE* f = fopen(path, "r");
+  if (!f) return CSL_E_INVALID;
+  char line[512];
+  int version = -1, n_read = 0;
+  std::map<Key, int> rec;
+  while (fgets(line, sizeof(line), f)) {
+    if (line[0] == '#') {
+      sscanf(line, "# csl_gemm_f32 plans: hipblaslt %d", &version);
+      continue;
+    }
+    int ta, tb, batch, epi, idx;
+    long long m, n, k, lda, ldb, ldc, sa, sb, sc;
+    if (sscanf(line, "%d %d %lld %lld %lld %lld %lld %lld %d %lld %lld %lld %d %d", &ta, &tb, &m, &n, &k, &lda, &ldb, &ldc,
+               &batch, &sa, &sb, &sc, &epi, &idx) == 14 && idx >= 0) {
+      rec[Key(ta, tb, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, epi)] = idx;
+      n_read++;
+    }
+  }
+  fclose(f);
+  g.recorded.swap(rec);
+  g.recorded_version = version;   // compared with the loaded library's version when a plan is made
+  return n_read;
 }
 
 int csl_sum_slabs_f32(const float* slabs, int64_t n, int32_t n_slabs, float* out, void* stream) {
