@@ -123,7 +123,8 @@ int csl_sage_cat_rows_bwd_f32(const int32_t* self_ids, const int32_t* owned, con
  *               ( t < 0 ? gcat[~t, 0:H) : gcat[t, H:2H) / max(indptr[t+1] - indptr[t], 1) ),   mask_u = y ? y[u, :] > 0 : 1
  * for u < n_src, zero rows up to n_pad; colsum[c] = sum_u out[u, c].  No atomics, nothing to pre-zero, deterministic.
  * indptr: the slice's CSR row pointers (the forward's mean divisors).  H % 4 == 0.
- * scratch: csl_sage_cat_bwd_t_scratch(n_pad, H) floats. */
+ * scratch: csl_sage_cat_bwd_t_scratch(n_pad, H) floats = [blocks][H] per-block column sums.  colsum == NULL: they are
+ * left there for the caller's own second stage (csl_reduce_multi_f32 with nblk = scratch floats / H). */
 int64_t csl_sage_cat_bwd_t_scratch(int64_t n_pad, int32_t H);
 int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, const int32_t* indptr, const float* gcat,
                            int64_t ldg, const float* y, int64_t ldy, int64_t n_src, int64_t n_pad, float* out,
@@ -144,6 +145,19 @@ int64_t csl_softmax_ce_scratch(int64_t n);
 int csl_softmax_ce_f32(const float* logits, int64_t ldl, int64_t n, int32_t C, const int32_t* ids, const int32_t* rowmap,
                        const int64_t* labels, float scale, float* loss, float* grad, int64_t ldgr, float* scratch,
                        void* stream);
+
+/* The same with the two-stage reductions left open, for a caller that finishes every reduction of a step in one
+ * launch (csl_reduce_multi_f32): rows [n, n_pad) of grad are zeroed (GEMM operand padding); loss_partial[blocks] and,
+ * if given (C <= 256), col_partial[blocks][C] (column sums of grad: the bias gradient) with blocks = ceil(n_pad / 4). */
+int csl_softmax_ce_partial_f32(const float* logits, int64_t ldl, int64_t n, int64_t n_pad, int32_t C, const int32_t* ids,
+                               const int32_t* rowmap, const int64_t* labels, float scale, float* grad, int64_t ldgr,
+                               float* loss_partial, float* col_partial, void* stream);
+
+/* dst[j][c] = sum over b < nblk[j] of src[j][b * H[j] + c], c < H[j], for count <= 12 jobs in ONE launch: the second
+ * stage of a step's two-stage reductions (column sums, the loss with H = 1, the row slabs of a weight gradient).
+ * src / nblk / H / dst are HOST arrays. */
+int csl_reduce_multi_f32(int32_t count, const float* const* src, const int64_t* nblk, const int32_t* H, float* const* dst,
+                         void* stream);
 
 /* torch.optim.Adam's update (python/train.py:83; no weight decay, no amsgrad) for up to 24 parameter tensors in one
  * launch.  params / grads / exp_avg / exp_avg_sq: HOST arrays of `count` device pointers, numel[t] elements each;

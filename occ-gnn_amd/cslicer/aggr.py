@@ -20,7 +20,7 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_gat_logits_bwd_scratch", "csl_spmm_sum_compact_f32", "csl_sage_cat_rows_bwd_f32",
            "csl_sage_cat_bwd_t_f32", "csl_sage_cat_bwd_t_scratch", "csl_gemm_f32", "csl_gemm_last_error",
            "csl_sum_slabs_f32", "csl_sage_fwd_bwd_f32", "csl_sage_fwd_bwd_workspace", "csl_sage_last_error",
-           "csl_gemm_save_plans", "csl_gemm_load_plans"]
+           "csl_gemm_save_plans", "csl_gemm_load_plans", "csl_softmax_ce_partial_f32", "csl_reduce_multi_f32"]
 _ready = False
 
 

@@ -611,13 +611,16 @@ __host__ __device__ inline long long tb_rows(long long n_pad) {
 //   loss = -scale * sum_r log softmax(logits[r])[label_r],   grad[r, :] = scale * (softmax(logits[r]) - onehot(label_r))
 // label_r = labels[rowmap ? rowmap[ids[r]] : ids[r]] (ids = the seeds' node ids).  One wave per row (C <= 4096); a
 // block leaves the loss of its four rows in partial[block], k_colsum_finish (H = 1) adds the blocks up.
-__global__ __launch_bounds__(BLK) void k_softmax_ce(const float* __restrict__ logits, long long ldl, long long n, int C,
-                                                    const int* __restrict__ ids, const int* __restrict__ rowmap,
-                                                    const long long* __restrict__ labels, float scale,
-                                                    float* __restrict__ partial, float* __restrict__ grad, long long ldgr) {
+constexpr int SM_CMAX = 256;  // widest row whose per-block column sums fit the LDS tile below
+__global__ __launch_bounds__(BLK) void k_softmax_ce(const float* __restrict__ logits, long long ldl, long long n,
+                                                    long long n_pad, int C, const int* __restrict__ ids,
+                                                    const int* __restrict__ rowmap, const long long* __restrict__ labels,
+                                                    float scale, float* __restrict__ partial, float* __restrict__ grad,
+                                                    long long ldgr, float* __restrict__ colpart) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long r = (long long)blockIdx.x * (BLK / 64) + w;
   __shared__ float s_l[BLK / 64];
+  __shared__ float s_c[BLK / 64][SM_CMAX];
   float mine = 0.f;
   if (r < n) {
     const float* z = logits + r * ldl;
@@ -630,12 +633,63 @@ __global__ __launch_bounds__(BLK) void k_softmax_ce(const float* __restrict__ lo
     const long long node = ids[r];
     const long long lab = labels[rowmap ? (long long)rowmap[node] : node];
     const float inv = 1.0f / s;
-    for (int c = lane; c < C; c += 64) grad[r * ldgr + c] = scale * (expf(z[c] - m) * inv - (c == lab ? 1.f : 0.f));
+    for (int c = lane; c < C; c += 64) {
+      const float gv = scale * (expf(z[c] - m) * inv - (c == lab ? 1.f : 0.f));
+      grad[r * ldgr + c] = gv;
+      if (colpart) s_c[w][c] = gv;
+    }
     mine = scale * (logf(s) + m - z[lab]);
+  } else if (r < n_pad) {
+    // padding rows of the GEMM operand the gradient becomes
+    for (int c = lane; c < C; c += 64) grad[r * ldgr + c] = 0.f;
   }
+  if (colpart && r >= n)
+    for (int c = lane; c < C; c += 64) s_c[w][c] = 0.f;
   if (lane == 0) s_l[w] = mine;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = s_l[0] + s_l[1] + s_l[2] + s_l[3];
+  // the block's column sums of the gradient (the bias gradient's first stage)
+  if (colpart)
+    for (int c = threadIdx.x; c < C; c += BLK)
+      colpart[(long long)blockIdx.x * C + c] = (s_c[0][c] + s_c[1][c]) + (s_c[2][c] + s_c[3][c]);
+}
+
+// dst_j[c] = sum over b < nblk_j of src_j[b * H_j + c] for up to RM_MAX jobs in ONE launch: the second stage of every
+// two-stage reduction of a training step (bias column sums, the loss, the row slabs of the weight gradients) when the
+// results are only needed at the step's end -- one launch instead of one 5-9 us launch each.
+constexpr int RM_MAX = 12;
+struct ReduceJobs {
+  const float* src[RM_MAX];
+  float* dst[RM_MAX];
+  long long nblk[RM_MAX];
+  int H[RM_MAX];
+  int first_block[RM_MAX + 1];
+  int count;
+};
+__global__ __launch_bounds__(BLK) void k_reduce_multi(ReduceJobs jb) {
+  int j = 0;
+  while (j + 1 < jb.count && (int)blockIdx.x >= jb.first_block[j + 1]) j++;
+  const int H = jb.H[j];
+  const long long nblk = jb.nblk[j];
+  const float* __restrict__ partial = jb.src[j];
+  const int c = ((int)blockIdx.x - jb.first_block[j]) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  __shared__ float s_q[BLK];
+  float acc = 0.f;
+  if (c < H) {
+    constexpr int Q = BLK / 64, U = 8;
+    long long b = q;
+    for (; b + (U - 1) * Q < nblk; b += U * Q) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) v[u] = partial[(b + u * Q) * H + c];
+#pragma unroll
+      for (int u = 0; u < U; u++) acc += v[u];
+    }
+    for (; b < nblk; b += Q) acc += partial[b * H + c];
+  }
+  s_q[threadIdx.x] = acc;
+  __syncthreads();
+  if (q == 0 && c < H) jb.dst[j][c] = s_q[threadIdx.x] + s_q[threadIdx.x + 64] + s_q[threadIdx.x + 128] + s_q[threadIdx.x + 192];
 }
 
 // ---- Adam (python/train.py:83 torch.optim.Adam, no weight decay, no amsgrad) over every parameter tensor of the
@@ -927,7 +981,7 @@ int64_t csl_sage_cat_bwd_t_scratch(int64_t n_pad, int32_t H) {
 int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, const int32_t* indptr, const float* gcat,
                            int64_t ldg, const float* y, int64_t ldy, int64_t n_src, int64_t n_pad, float* out,
                            int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream) {
-  if (n_src < 0 || n_pad < n_src || H < 4 || H % 4 != 0 || !colsum) return CSL_E_INVALID;
+  if (n_src < 0 || n_pad < n_src || H < 4 || H % 4 != 0) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const long long rpb = tb_rows(n_pad);
   const long long blocks = (n_pad + rpb - 1) / rpb;
@@ -940,7 +994,8 @@ int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, co
                        (long long)ldg, y, (long long)ldy, (long long)n_src, (long long)n_pad, out, (long long)ldo, scratch,
                        (int)H, rpb);
   }
-  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((H + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, (int)H, colsum);
+  // colsum == NULL: the per-block sums stay in scratch[blocks][H] for the caller's own second stage (csl_reduce_multi_f32)
+  if (colsum) hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((H + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, (int)H, colsum);
   return done();
 }
 
@@ -982,9 +1037,46 @@ int csl_softmax_ce_f32(const float* logits, int64_t ldl, int64_t n, int32_t C, c
   if (blocks > 0) {
     if (!logits || !ids || !labels || !grad || !scratch || ldl < C || ldgr < C) return CSL_E_INVALID;
     hipLaunchKernelGGL(k_softmax_ce, dim3((unsigned)blocks), dim3(BLK), 0, st, logits, (long long)ldl, (long long)n,
-                       (int)C, ids, rowmap, (const long long*)labels, scale, scratch, grad, (long long)ldgr);
+                       (long long)n, (int)C, ids, rowmap, (const long long*)labels, scale, scratch, grad, (long long)ldgr,
+                       (float*)nullptr);
   }
   hipLaunchKernelGGL(k_colsum_finish, dim3(1), dim3(BLK), 0, st, scratch, blocks, 1, loss);
+  return done();
+}
+
+int csl_softmax_ce_partial_f32(const float* logits, int64_t ldl, int64_t n, int64_t n_pad, int32_t C, const int32_t* ids,
+                               const int32_t* rowmap, const int64_t* labels, float scale, float* grad, int64_t ldgr,
+                               float* loss_partial, float* col_partial, void* stream) {
+  if (n < 0 || n_pad < n || C < 1 || (col_partial && C > SM_CMAX)) return CSL_E_INVALID;
+  const long long blocks = (n_pad + BLK / 64 - 1) / (BLK / 64);
+  if (blocks > 0) {
+    if (!grad || !loss_partial || ldgr < C || (n > 0 && (!logits || !ids || !labels || ldl < C))) return CSL_E_INVALID;
+    hipLaunchKernelGGL(k_softmax_ce, dim3((unsigned)blocks), dim3(BLK), 0, (hipStream_t)stream, logits, (long long)ldl,
+                       (long long)n, (long long)n_pad, (int)C, ids, rowmap, (const long long*)labels, scale, loss_partial,
+                       grad, (long long)ldgr, col_partial);
+  }
+  return done();
+}
+
+int csl_reduce_multi_f32(int32_t count, const float* const* src, const int64_t* nblk, const int32_t* H, float* const* dst,
+                         void* stream) {
+  if (count < 0 || count > RM_MAX) return CSL_E_INVALID;
+  if (count == 0) return CSL_OK;
+  if (!src || !nblk || !H || !dst) return CSL_E_INVALID;
+  ReduceJobs jb;
+  int at = 0;
+  jb.count = 0;
+  for (int j = 0; j < count; j++) {
+    if (H[j] < 0 || nblk[j] < 0) return CSL_E_INVALID;
+    if (H[j] == 0) continue;
+    if (!dst[j] || (nblk[j] > 0 && !src[j])) return CSL_E_INVALID;
+    const int k = jb.count++;
+    jb.src[k] = src[j], jb.dst[k] = dst[j], jb.nblk[k] = nblk[j], jb.H[k] = H[j];
+    jb.first_block[k] = at;
+    at += (H[j] + 63) / 64;
+  }
+  jb.first_block[jb.count] = at;
+  if (at > 0) hipLaunchKernelGGL(k_reduce_multi, dim3((unsigned)at), dim3(BLK), 0, (hipStream_t)stream, jb);
   return done();
 }
 

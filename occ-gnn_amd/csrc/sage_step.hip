@@ -10,11 +10,12 @@
 // Per model layer k (deepest hop first; slice k = the engine's layer n_layers-1-k, graph mode, FLAG_TRANSPOSE):
 //   forward   cat_k = [x[self] | mean_{CSR row} x[src]]       csl_sage_cat_f32 (k = 0 reads the resident feature table
 //             y_k   = cat_k W_k^T + b_k (ReLU for k < L-1)     through the slice's in_nodes)      + csl_gemm_f32
-//   loss      csl_softmax_ce_f32 on y_{L-1} (forward and gradient in one pass)
-//   backward  gW_k  = gy_k^T cat_k (row slabs + sum)           csl_gemm_f32 (batched) + csl_sum_slabs_f32
+//   loss      csl_softmax_ce_partial_f32 on y_{L-1} (forward, gradient = the top layer's padded gy, bias column sums)
+//   backward  gW_k  = gy_k^T cat_k (row slabs)                 csl_gemm_f32 (batched)
 //             gcat  = gy_k W_k                                 csl_gemm_f32
 //             gy_{k-1}, gb_{k-1} = gather of gcat over the slice by source, ReLU mask of y_{k-1}, row padding and
 //                                  bias column sums in the same pass                   csl_sage_cat_bwd_t_f32
+//   the second stage of every reduction above (bias sums, slab sums, the loss): ONE launch (csl_reduce_multi_f32)
 // Rows are padded to a multiple of `row_pad` so that GEMM shapes repeat from minibatch to minibatch.
 #include <hip/hip_runtime.h>
 
@@ -35,13 +36,20 @@ inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }  // every buffer
 
 struct Layout {
   int64_t cat[CSL_MAX_LAYERS], y[CSL_MAX_LAYERS], gy[CSL_MAX_LAYERS], gcat[CSL_MAX_LAYERS], mp[CSL_MAX_LAYERS];
-  int64_t g, slabs, scratch, total;
+  // first stages of the step's reductions, each in a buffer of its own: they are all finished by ONE launch at the end
+  int64_t slabs[CSL_MAX_LAYERS];    // [n_slabs][out][2 in] of a layer whose weight gradient is computed in row slabs
+  int64_t bpart[CSL_MAX_LAYERS];    // [blocks][out]: per-block column sums behind gb_k (k < L-1: from layer k+1's gather)
+  int64_t bblocks[CSL_MAX_LAYERS];
+  int64_t lpart, lblocks;           // [blocks]: the loss
+  bool slabbed[CSL_MAX_LAYERS];
+  bool top_cols;                    // the softmax pass also leaves the top layer's bias column sums
+  int64_t g, scratch, total;
 };
 
 // bump allocation of the step's buffers (floats); returns false for an unsupported model
 bool lay_out(int32_t L, const int32_t* dims, const csl_sage_slice* sl, int64_t row_pad, int32_t n_slabs, Layout& o) {
   if (L < 1 || L > CSL_MAX_LAYERS || n_slabs < 1) return false;
-  int64_t at = 0, scratch = 0, slabs = 0;
+  int64_t at = 0, scratch = 0;
   for (int k = 0; k < L; k++) {
     const int64_t in = dims[k], out = dims[k + 1];
     if (in < 4 || in % 4 != 0 || out < 1 || sl[k].n_out < 0 || sl[k].n_in < 0) return false;
@@ -53,15 +61,30 @@ bool lay_out(int32_t L, const int32_t* dims, const csl_sage_slice* sl, int64_t r
     o.y[k] = at, at += up4(mp * out);
     o.gy[k] = at, at += up4(mp * out);
     o.gcat[k] = at, at += k > 0 ? up4(mp * 2 * in) : 0;
-    const int64_t s1 = csl_relu_bwd_colsum_scratch(mp, (int32_t)out), s2 = csl_sage_cat_bwd_t_scratch(mp, (int32_t)out);
-    if (s1 > scratch) scratch = s1;
-    if (s2 > scratch) scratch = s2;
-    if (out * 2 * in * n_slabs > slabs) slabs = out * 2 * in * n_slabs;
+    const int64_t wn = out * 2 * in;
+    o.slabbed[k] = row_pad > 0 && mp >= row_pad && n_slabs > 1 && mp % n_slabs == 0 && wn % 4 == 0;
+    o.slabs[k] = at, at += o.slabbed[k] ? up4(wn * n_slabs) : 0;
+    // gb_k's first stage: written by layer k+1's gather (k < L-1) or by the loss pass / relu_bwd_colsum (k = L-1)
+    const int64_t part = k + 1 < L ? csl_sage_cat_bwd_t_scratch(mp, (int32_t)out) : 0;
+    o.bblocks[k] = out > 0 ? part / out : 0;
+    o.bpart[k] = at, at += up4(part);
   }
-  const int64_t s3 = csl_softmax_ce_scratch(sl[L - 1].n_out);
-  if (s3 > scratch) scratch = s3;
-  o.g = at, at += up4(sl[L - 1].n_out * dims[L]);
-  o.slabs = at, at += up4(slabs);
+  {
+    const int k = L - 1;
+    const int64_t C = dims[L], rows = o.mp[k];
+    o.top_cols = C <= 256;
+    o.lblocks = (rows + 3) / 4;
+    o.lpart = at, at += up4(o.lblocks);
+    if (o.top_cols) {
+      o.bblocks[k] = o.lblocks;
+      o.bpart[k] = at, at += up4(o.lblocks * C);
+    } else {
+      scratch = csl_relu_bwd_colsum_scratch(rows, (int32_t)C);
+    }
+    // the gradient w.r.t. the logits IS the top layer's (padded) gy when the loss pass pads it; else a buffer of its own
+    o.g = o.top_cols ? o.gy[k] : at;
+    at += o.top_cols ? 0 : up4(sl[k].n_out * C);
+  }
   o.scratch = at, at += up4(scratch);
   o.total = at;
   return true;
@@ -126,13 +149,31 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
     STEP(csl_gemm_f32(0, 1, mp, out, 2 * (int64_t)in, ws + o.cat[k], 2 * (int64_t)in, 0, weights[k], 2 * (int64_t)in, 0,
                       ws + o.y[k], out, 0, 1, biases[k], k + 1 < L ? 1 : 0, stream));
   }
-  // ---- loss and its gradient w.r.t. the logits; padded + bias column sums for the top layer
+  // the second stages, collected: (source, blocks, width, destination)
+  const float* r_src[12];
+  float* r_dst[12];
+  int64_t r_nblk[12];
+  int32_t r_h[12];
+  int nr = 0;
+  auto defer = [&](const float* src, int64_t nblk, int32_t h, float* dst) {
+    r_src[nr] = src, r_nblk[nr] = nblk, r_h[nr] = h, r_dst[nr] = dst;
+    nr++;
+  };
+  // ---- loss and its gradient w.r.t. the logits (written as the top layer's padded gy), bias column sums alongside
   k = L - 1;
   {
     const int32_t C = dims[L];
     const int64_t m = sl[k].n_out;
-    STEP(csl_softmax_ce_f32(ws + o.y[k], C, m, C, seed_ids, nullptr, labels, scale, loss, ws + o.g, C, ws + o.scratch, stream));
-    STEP(csl_relu_bwd_colsum_f32(ws + o.g, C, nullptr, 0, m, o.mp[k], ws + o.gy[k], C, gb[k], ws + o.scratch, C, stream));
+    if (o.top_cols) {
+      STEP(csl_softmax_ce_partial_f32(ws + o.y[k], C, m, o.mp[k], C, seed_ids, nullptr, labels, scale, ws + o.gy[k], C,
+                                      ws + o.lpart, ws + o.bpart[k], stream));
+      defer(ws + o.bpart[k], o.bblocks[k], C, gb[k]);
+    } else {
+      STEP(csl_softmax_ce_partial_f32(ws + o.y[k], C, m, m, C, seed_ids, nullptr, labels, scale, ws + o.g, C, ws + o.lpart,
+                                      nullptr, stream));
+      STEP(csl_relu_bwd_colsum_f32(ws + o.g, C, nullptr, 0, m, o.mp[k], ws + o.gy[k], C, gb[k], ws + o.scratch, C, stream));
+    }
+    defer(ws + o.lpart, o.top_cols ? o.lblocks : (m + 3) / 4, 1, loss);  // (blocks of four rows the loss pass covered)
   }
   // ---- backward
   for (k = L - 1; k >= 0; k--) {
@@ -140,11 +181,11 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
     const int64_t mp = o.mp[k], wn = (int64_t)out * 2 * in;
     if (mp == 0) {
       if (hipMemsetAsync(gW[k], 0, sizeof(float) * wn, (hipStream_t)stream) != hipSuccess) return CSL_E_HIP;
-    } else if (row_pad > 0 && mp >= row_pad && mp % n_slabs == 0 && wn % 4 == 0 && n_slabs > 1 && ((uintptr_t)gW[k] & 15) == 0) {
+    } else if (o.slabbed[k]) {
       const int64_t rs = mp / n_slabs;
       STEP(csl_gemm_f32(1, 0, out, 2 * (int64_t)in, rs, ws + o.gy[k], out, rs * out, ws + o.cat[k], 2 * (int64_t)in,
-                        rs * 2 * in, ws + o.slabs, 2 * (int64_t)in, wn, n_slabs, nullptr, 0, stream));
-      STEP(csl_sum_slabs_f32(ws + o.slabs, wn, n_slabs, gW[k], stream));
+                        rs * 2 * in, ws + o.slabs[k], 2 * (int64_t)in, wn, n_slabs, nullptr, 0, stream));
+      defer(ws + o.slabs[k], n_slabs, (int32_t)wn, gW[k]);
     } else {
       STEP(csl_gemm_f32(1, 0, out, 2 * (int64_t)in, mp, ws + o.gy[k], out, 0, ws + o.cat[k], 2 * (int64_t)in, 0, gW[k],
                         2 * (int64_t)in, 0, 1, nullptr, 0, stream));
@@ -156,11 +197,17 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
     }
     STEP(csl_gemm_f32(0, 0, mp, 2 * (int64_t)in, out, ws + o.gy[k], out, 0, weights[k], 2 * (int64_t)in, 0, ws + o.gcat[k],
                       2 * (int64_t)in, 0, 1, nullptr, 0, stream));
-    // gradient w.r.t. layer k-1's pre-activation output (= this layer's input x), padded like its GEMM operand
+    // gradient w.r.t. layer k-1's pre-activation output (= this layer's input x), padded like its GEMM operand;
+    // its column sums (gb_{k-1}) stay as per-block partials
     STEP(csl_sage_cat_bwd_t_f32(sl[k].t_indptr, sl[k].t_indices, sl[k].indptr, ws + o.gcat[k], 2 * (int64_t)in,
-                                ws + o.y[k - 1], in, sl[k].n_in, o.mp[k - 1], ws + o.gy[k - 1], in, gb[k - 1],
-                                ws + o.scratch, in, stream));
+                                ws + o.y[k - 1], in, sl[k].n_in, o.mp[k - 1], ws + o.gy[k - 1], in, nullptr,
+                                ws + o.bpart[k - 1], in, stream));
+    if (o.bblocks[k - 1] > 0) defer(ws + o.bpart[k - 1], o.bblocks[k - 1], in, gb[k - 1]);
+    else if (hipMemsetAsync(gb[k - 1], 0, sizeof(float) * in, (hipStream_t)stream) != hipSuccess) return CSL_E_HIP;
   }
+  // ---- every deferred second stage (bias sums, weight-gradient slabs, the loss) in one launch
+  k = -1;
+  STEP(csl_reduce_multi_f32(nr, r_src, r_nblk, r_h, r_dst, stream));
   return CSL_OK;
 }
 
