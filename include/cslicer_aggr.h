@@ -86,6 +86,24 @@ int csl_gat_logits_bwd_f32(const float* z, const float* attn_l, const float* att
                            const float* g_er, int64_t n, int32_t H, int32_t D, float* g_z, float* g_attn_l,
                            float* g_attn_r, float* scratch, void* stream);
 
+/* the same with g_z ACCUMULATED (accumulate != 0: g_z += ...), on top of csl_gat_bwd_f32's share of the gradient of z:
+ * one buffer and no separate addition for z's two consumers */
+int csl_gat_logits_bwd_acc_f32(const float* z, const float* attn_l, const float* attn_r, const float* g_el,
+                               const float* g_er, int64_t n, int32_t H, int32_t D, float* g_z, int32_t accumulate,
+                               float* g_attn_l, float* g_attn_r, float* scratch, void* stream);
+
+/* GAT layer epilogue (DistGATConv: out[v] = sum_u alpha(u -> v) z[u] + bias, ELU between layers) from the aggregation's
+ * (s [n,H], n [n,H*D]):  out[r, h, :] = act(n[r, h, :] / max(s[r, h], 1e-30) + bias[h, :]),  act = ELU if elu else identity.
+ * Backward: p = g .* act'(out);  g_n = p / s;  g_s[r, h] = -sum_d g_n[r, h, d] n[r, h, d] / s[r, h];  g_bias = column
+ * sums of p (two-stage; scratch: csl_gat_finish_bwd_scratch(n, H, D) floats).  D % 4 == 0, D <= 256, dense rows (g may
+ * have a leading dimension ldg), 16-byte aligned. */
+int csl_gat_finish_fwd_f32(const float* n_in, const float* s_in, const float* bias, int64_t n, int32_t H, int32_t D,
+                           int32_t elu, float* out, void* stream);
+int64_t csl_gat_finish_bwd_scratch(int64_t n, int32_t H, int32_t D);
+int csl_gat_finish_bwd_f32(const float* g, int64_t ldg, const float* out, const float* n_in, const float* s_in, int64_t n,
+                           int32_t H, int32_t D, int32_t elu, float* g_n, float* g_s, float* g_bias, float* scratch,
+                           void* stream);
+
 /* ---- fused GraphSAGE layer pieces (DistSageConv.forward, python/layers/dist_sageconv.py:42-84) ----
  *
  * csl_sage_cat_f32: the operand of Linear(2*in, out) in one pass (self_gather + gather/mean + concat,

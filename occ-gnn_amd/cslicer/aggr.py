@@ -20,7 +20,8 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_gat_logits_bwd_scratch", "csl_spmm_sum_compact_f32", "csl_sage_cat_rows_bwd_f32",
            "csl_sage_cat_bwd_t_f32", "csl_sage_cat_bwd_t_scratch", "csl_gemm_f32", "csl_gemm_last_error",
            "csl_sum_slabs_f32", "csl_sage_fwd_bwd_f32", "csl_sage_fwd_bwd_workspace", "csl_sage_last_error",
-           "csl_gemm_save_plans", "csl_gemm_load_plans", "csl_softmax_ce_partial_f32", "csl_reduce_multi_f32"]
+           "csl_gemm_save_plans", "csl_gemm_load_plans", "csl_softmax_ce_partial_f32", "csl_reduce_multi_f32",
+           "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch"]
 _ready = False
 
 
@@ -64,6 +65,11 @@ def _lib():
         L.csl_sage_fwd_bwd_f32.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, i64, i32, vp, vp, vp, i64, vp]
         L.csl_sage_last_error.restype = C.c_char_p
         L.csl_gemm_save_plans.argtypes = [C.c_char_p]
+        L.csl_gat_logits_bwd_acc_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp]
+        L.csl_gat_finish_fwd_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
+        L.csl_gat_finish_bwd_f32.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]
+        L.csl_gat_finish_bwd_scratch.argtypes = [i64, i32, i32]
+        L.csl_gat_finish_bwd_scratch.restype = i64
         L.csl_gemm_load_plans.argtypes = [C.c_char_p]
         _ready = True
     return L
@@ -526,6 +532,87 @@ class GatLogits(torch.autograd.Function):
                                       C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr() + 4 * H * D),
                                       C.c_void_p(buf.data_ptr() + 8 * H * D), _stream()), "csl_gat_logits_bwd_f32")
         return g_z, buf[:H * D].view(H, D), buf[H * D:2 * H * D].view(H, D)
+
+
+class GatLayerLocal(torch.autograd.Function):
+    """A whole DistGATConv layer (+ ELU) of a single part (nothing to exchange) as ONE autograd node:
+    z = x W^T (library GEMM on the row-padded input), attention logits (csl_gat_logits_fwd_f32), destination logits
+    (row gather), the fused edge-softmax aggregation (csl_gat_fwd_f32) and the epilogue act(n / s + bias)
+    (csl_gat_finish_fwd_f32).  Backward: epilogue (csl_gat_finish_bwd_f32: g_n, g_s, bias gradient), aggregation
+    (csl_gat_bwd_f32: atomics into ONE zeroed g_z), logits (csl_gat_logits_bwd_acc_f32 adds its share to the same
+    g_z), then the two GEMMs.  As separate autograd nodes the same layer ran a dozen torch broadcast / reduction /
+    accumulation kernels and three 90 MB gradient additions per step (profiles/r2_e2e_gat)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, attn_l, attn_r, bias, indptr, indices, self_ids_in, n_out, slope, elu, row_pad,
+                weight_grad):
+        H, D = attn_l.shape
+        Cw = H * D
+        n_in, mp = x.shape[0], x.shape[0]
+        if row_pad and n_in >= row_pad:
+            mp = (n_in + row_pad - 1) // row_pad * row_pad
+        x = _f32(x)
+        if mp != n_in or not x.is_contiguous():
+            xp = torch.empty((mp, x.shape[1]), dtype=torch.float32, device=x.device)
+            xp[:n_in].copy_(x)
+            if mp != n_in:
+                xp[n_in:].zero_()
+        else:
+            xp = x
+        z = xp @ weight.t()                                         # [mp, H*D]
+        al, ar, b = _f32(attn_l).contiguous(), _f32(attn_r).contiguous(), _f32(bias).contiguous()
+        indptr, indices, self_ids_in = _i32(indptr), _i32(indices), _i32(self_ids_in)
+        dev = x.device
+        L = _lib()
+        el = torch.empty((n_in, H), dtype=torch.float32, device=dev)
+        er = torch.empty((n_in, H), dtype=torch.float32, device=dev)
+        _chk(L.csl_gat_logits_fwd_f32(_p(z), _p(al), _p(ar), n_in, H, D, _p(el), _p(er), _stream()),
+             "csl_gat_logits_fwd_f32")
+        er_out = gather_rows(er, self_ids_in)                       # logits of the destinations, [n_out, H]
+        m = torch.empty((n_out, H), dtype=torch.float32, device=dev)
+        s = torch.empty((n_out, H), dtype=torch.float32, device=dev)
+        n = torch.empty((n_out, Cw), dtype=torch.float32, device=dev)
+        _chk(L.csl_gat_fwd_f32(_p(indptr), _p(indices), n_out, _p(el), _p(er_out), _p(z), H, D, slope, _p(m), _p(s), _p(n),
+                               _stream()), "csl_gat_fwd_f32")
+        out = torch.empty((n_out, Cw), dtype=torch.float32, device=dev)
+        _chk(L.csl_gat_finish_fwd_f32(_p(n), _p(s), _p(b), n_out, H, D, 1 if elu else 0, _p(out), _stream()),
+             "csl_gat_finish_fwd_f32")
+        ctx.save_for_backward(xp, weight, al, ar, z, el, er_out, m, s, n, out, indptr, indices, self_ids_in)
+        ctx.cfg = (n_in, n_out, H, D, slope, bool(elu), weight_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, weight, al, ar, z, el, er_out, m, s, n, out, indptr, indices, self_ids_in = ctx.saved_tensors
+        n_in, n_out, H, D, slope, elu, weight_grad = ctx.cfg
+        Cw, dev = H * D, z.device
+        L = _lib()
+        g = _f32(g)
+        if g.stride(-1) != 1 or g.stride(0) % 4:
+            g = g.contiguous()
+        g_n = torch.empty((n_out, Cw), dtype=torch.float32, device=dev)
+        g_s = torch.empty((n_out, H), dtype=torch.float32, device=dev)
+        buf = torch.empty((3 * Cw + max(int(L.csl_gat_finish_bwd_scratch(n_out, H, D)),
+                                        2 * int(L.csl_gat_logits_bwd_scratch(n_in, H, D)), 4),), dtype=torch.float32,
+                          device=dev)
+        g_bias, g_al, g_ar = buf[:Cw], buf[Cw:2 * Cw].view(H, D), buf[2 * Cw:3 * Cw].view(H, D)
+        scratch = C.c_void_p(buf.data_ptr() + 12 * Cw)
+        _chk(L.csl_gat_finish_bwd_f32(_p(g), g.stride(0), _p(out), _p(n), _p(s), n_out, H, D, 1 if elu else 0, _p(g_n),
+                                      _p(g_s), _p(g_bias), scratch, _stream()), "csl_gat_finish_bwd_f32")
+        # ONE gradient buffer for z (padded like the GEMM operand): the aggregation's atomics, then the logits' share
+        g_z = torch.zeros((z.shape[0], Cw), dtype=torch.float32, device=dev)
+        g_el = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
+        g_er_out = torch.empty((n_out, H), dtype=torch.float32, device=dev)
+        _chk(L.csl_gat_bwd_f32(_p(indptr), _p(indices), n_out, _p(el), _p(er_out), _p(z), H, D, slope, _p(m), _p(g_s),
+                               _p(g_n), _p(g_el), _p(g_er_out), _p(g_z), _stream()), "csl_gat_bwd_f32")
+        g_er = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
+        scatter_add_rows_(g_er, self_ids_in, g_er_out)              # (a node is the self source of one destination)
+        _chk(L.csl_gat_logits_bwd_acc_f32(_p(z), _p(al), _p(ar), _p(g_el), _p(g_er), n_in, H, D, _p(g_z), 1,
+                                          C.c_void_p(g_al.data_ptr()), C.c_void_p(g_ar.data_ptr()), scratch, _stream()),
+             "csl_gat_logits_bwd_acc_f32")
+        gw = weight_grad(g_z, xp)
+        gx = (g_z @ weight)[:n_in] if ctx.needs_input_grad[0] else None
+        return gx, gw, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None
 
 
 def attention_gather(indptr, indices, u_in, v_in, n_rows):

@@ -470,9 +470,20 @@ class DistGATConv(nn.Module):
         el, er = aggr.GatLogits.apply(z, self.attn_l, self.attn_r)
         return z, el, er
 
-    def forward_parts(self, sl, x):
+    def forward_parts(self, sl, x, elu=False):
         """sl[g]: Slice of part g, x[g]: features of sl[g].in_nodes.  Returns per part the [n_owned, H*D]
-        output rows of the nodes it owns (frontier order)."""
+        output rows of the nodes it owns (frontier order); elu: apply the ELU that follows a hidden layer."""
+        parts = sorted(sl.keys())
+        if len(parts) == 1 and sl[parts[0]].n_parts == 1 and x[parts[0]].is_cuda and not _NO_LOCAL_FUSE:
+            # one part holding every node: the whole layer (+ ELU) as one autograd node
+            g = parts[0]
+            return {g: aggr.GatLayerLocal.apply(x[g], self.fc.weight, self.attn_l, self.attn_r, self.bias, sl[g].indptr,
+                                                sl[g].indices, sl[g].self_ids_in, sl[g].n_out, self.slope, bool(elu),
+                                                ROW_PAD, _weight_grad)}
+        out = self._forward_parts(sl, x)
+        return {g: torch.nn.functional.elu(v) for g, v in out.items()} if elu else out
+
+    def _forward_parts(self, sl, x):
         parts = sorted(sl.keys())
         H, D = self.H, self.D
         if len(parts) == 1 and sl[parts[0]].n_parts == 1:
@@ -569,10 +580,8 @@ class DistGATModel(nn.Module):
         parts = sorted(slices[0].keys())
         x = {g: feats[g] for g in parts}
         for k, conv in enumerate(self.convs):
-            x = conv.forward_parts(slices[L - 1 - k], x)
-            if k + 1 < len(self.convs):
-                x = {g: torch.nn.functional.elu(x[g]) for g in parts}
-            else:
+            x = conv.forward_parts(slices[L - 1 - k], x, elu=k + 1 < len(self.convs))
+            if k + 1 == len(self.convs):
                 x = {g: x[g].view(-1, self.heads, conv.D).mean(1)[:, :self.n_classes] for g in parts}
         return x
 

@@ -762,7 +762,8 @@ __global__ __launch_bounds__(BLK) void k_gat_logits_bwd(const float* __restrict_
                                                         const float* __restrict__ ar, const float* __restrict__ g_el,
                                                         const float* __restrict__ g_er, long long n, int H, int D,
                                                         float* __restrict__ g_z, float* __restrict__ part_l,
-                                                        float* __restrict__ part_r, long long rows_per_block) {
+                                                        float* __restrict__ part_r, long long rows_per_block,
+                                                        int accumulate) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int C = H * D, gsz = D / 4, lpc = (64 / gsz) * gsz;
   const long long r0 = (long long)blockIdx.x * rows_per_block;
@@ -783,6 +784,7 @@ __global__ __launch_bounds__(BLK) void k_gat_logits_bwd(const float* __restrict_
       const float4 zv = *reinterpret_cast<const float4*>(z + r * C + c);
       float4 o;
       o.x = gl_ * a.x + gr_ * b.x, o.y = gl_ * a.y + gr_ * b.y, o.z = gl_ * a.z + gr_ * b.z, o.w = gl_ * a.w + gr_ * b.w;
+      if (accumulate) add4(o, *reinterpret_cast<const float4*>(g_z + r * C + c));  // on top of the aggregation's share
       *reinterpret_cast<float4*>(g_z + r * C + c) = o;
       pl.x += gl_ * zv.x, pl.y += gl_ * zv.y, pl.z += gl_ * zv.z, pl.w += gl_ * zv.w;
       pr.x += gr_ * zv.x, pr.y += gr_ * zv.y, pr.z += gr_ * zv.z, pr.w += gr_ * zv.w;
@@ -798,6 +800,77 @@ __global__ __launch_bounds__(BLK) void k_gat_logits_bwd(const float* __restrict_
       }
       *reinterpret_cast<float4*>(part_l + (long long)blockIdx.x * C + c) = pl;
       *reinterpret_cast<float4*>(part_r + (long long)blockIdx.x * C + c) = pr;
+    }
+  }
+}
+
+// ---- GAT layer epilogue: out = act(n / s + bias) from the aggregation's (s, n) (DistGATConv: out[v] = sum_u alpha z[u]
+// + bias; ELU between layers), and its backward -- with torch ops this was a division, an add, an ELU and their
+// autograd nodes with broadcasts and reductions (a dozen launches per layer).  One wave per row, a lane owns 4
+// consecutive columns, heads are groups of D / 4 lanes (the layout of k_gat_logits_*).
+__global__ __launch_bounds__(BLK) void k_gat_finish_fwd(const float* __restrict__ nsum, const float* __restrict__ ssum,
+                                                        const float* __restrict__ bias, long long n, int H, int D,
+                                                        int elu, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int C = H * D, gsz = D / 4, lpc = (64 / gsz) * gsz;
+  for (int c0 = 0; c0 < C; c0 += lpc * 4) {
+    const int c = c0 + lane * 4;
+    if (lane >= lpc || c >= C) continue;
+    const float inv = 1.f / fmaxf(ssum[r * H + c / D], 1e-30f);
+    float4 v = *reinterpret_cast<const float4*>(nsum + r * C + c);
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
+    v.x = v.x * inv + b.x, v.y = v.y * inv + b.y, v.z = v.z * inv + b.z, v.w = v.w * inv + b.w;
+    if (elu) v.x = v.x > 0.f ? v.x : expm1f(v.x), v.y = v.y > 0.f ? v.y : expm1f(v.y), v.z = v.z > 0.f ? v.z : expm1f(v.z), v.w = v.w > 0.f ? v.w : expm1f(v.w);
+    *reinterpret_cast<float4*>(out + r * C + c) = v;
+  }
+}
+// backward: p = g .* act'(out) (ELU: out > 0 ? 1 : out + 1);  g_n = p / s;  g_s[r, h] = -sum_d g_n n / s;
+// per-block column sums of p (the bias gradient's first stage) to part[block][C]
+__global__ __launch_bounds__(BLK) void k_gat_finish_bwd(const float* __restrict__ g, long long ldg,
+                                                        const float* __restrict__ out, const float* __restrict__ nsum,
+                                                        const float* __restrict__ ssum, long long n, int H, int D, int elu,
+                                                        float* __restrict__ g_n, float* __restrict__ g_s,
+                                                        float* __restrict__ part, long long rows_per_block) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int C = H * D, gsz = D / 4, lpc = (64 / gsz) * gsz, gl = lane % gsz;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r_end = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  __shared__ float s_p[BLK * 4];
+  for (int c0 = 0; c0 < C; c0 += lpc * 4) {  // block-uniform
+    const int c = c0 + lane * 4;
+    const bool on = lane < lpc && c < C;
+    const int h = on ? c / D : 0;
+    float4 colacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long r = r0 + w; r < r_end; r += BLK / 64) {  // wave-uniform
+      float dot = 0.f;
+      if (on) {
+        float4 p = *reinterpret_cast<const float4*>(g + r * ldg + c);
+        if (elu) {
+          const float4 o = *reinterpret_cast<const float4*>(out + r * C + c);
+          p.x *= o.x > 0.f ? 1.f : o.x + 1.f, p.y *= o.y > 0.f ? 1.f : o.y + 1.f;
+          p.z *= o.z > 0.f ? 1.f : o.z + 1.f, p.w *= o.w > 0.f ? 1.f : o.w + 1.f;
+        }
+        add4(colacc, p);
+        const float inv = 1.f / fmaxf(ssum[r * H + h], 1e-30f);
+        const float4 nv = *reinterpret_cast<const float4*>(nsum + r * C + c);
+        p.x *= inv, p.y *= inv, p.z *= inv, p.w *= inv;
+        *reinterpret_cast<float4*>(g_n + r * C + c) = p;
+        dot = -(p.x * nv.x + p.y * nv.y + p.z * nv.z + p.w * nv.w) * inv;
+      }
+      for (int o = 1; o < gsz; o <<= 1) {  // segmented tree over the head's lane group
+        const float t = __shfl_down(dot, o);
+        if (gl + o < gsz) dot += t;
+      }
+      if (on && gl == 0) g_s[r * H + h] = dot;
+    }
+    __syncthreads();
+    reinterpret_cast<float4*>(s_p)[threadIdx.x] = colacc;
+    __syncthreads();
+    if (w == 0 && on) {
+      for (int k = 1; k < BLK / 64; k++) add4(colacc, reinterpret_cast<float4*>(s_p)[k * 64 + lane]);
+      *reinterpret_cast<float4*>(part + (long long)blockIdx.x * C + c) = colacc;
     }
   }
 }
@@ -852,6 +925,40 @@ int csl_spmm_sum_compact_f32(const int32_t* indptr, const int32_t* indices, cons
 
 // gradient of csl_sage_cat_f32's merged-sums form: gx [n_x, H] and gagg [n_agg, H] are zeroed here, then
 // gx[self_ids[r]] = gcat[r, 0:H) and gagg[owned[r]] = gcat[r, H:2H) / max(deg[r], 1) (both index lists are unique)
+int csl_gat_finish_fwd_f32(const float* n_in, const float* s_in, const float* bias, int64_t n, int32_t H, int32_t D,
+                           int32_t elu, float* out, void* stream) {
+  if (n < 0 || H < 1 || D < 4 || D % 4 != 0 || D > 256) return CSL_E_INVALID;
+  if (n == 0) return CSL_OK;
+  if (!n_in || !s_in || !bias || !out || !aligned16(n_in) || !aligned16(bias) || !aligned16(out)) return CSL_E_INVALID;
+  hipLaunchKernelGGL(k_gat_finish_fwd, dim3((unsigned)((n + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, (hipStream_t)stream,
+                     n_in, s_in, bias, (long long)n, (int)H, (int)D, (int)(elu != 0), out);
+  return done();
+}
+
+int64_t csl_gat_finish_bwd_scratch(int64_t n, int32_t H, int32_t D) {
+  const long long rpb = rb_rows(n);
+  return ((n + rpb - 1) / rpb) * (int64_t)H * D;
+}
+
+int csl_gat_finish_bwd_f32(const float* g, int64_t ldg, const float* out, const float* n_in, const float* s_in, int64_t n,
+                           int32_t H, int32_t D, int32_t elu, float* g_n, float* g_s, float* g_bias, float* scratch,
+                           void* stream) {
+  if (n < 0 || H < 1 || D < 4 || D % 4 != 0 || D > 256 || !g_bias) return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = H * D;
+  const long long rpb = rb_rows(n);
+  const long long blocks = (n + rpb - 1) / rpb;
+  if (blocks > 0) {
+    if (!g || ldg < C || ldg % 4 != 0 || !n_in || !s_in || !g_n || !g_s || !scratch || (elu && !out) || !aligned16(g) ||
+        !aligned16(n_in) || !aligned16(g_n) || !aligned16(scratch) || (out && !aligned16(out)))
+      return CSL_E_INVALID;
+    hipLaunchKernelGGL(k_gat_finish_bwd, dim3((unsigned)blocks), dim3(BLK), 0, st, g, (long long)ldg, out, n_in, s_in,
+                       (long long)n, (int)H, (int)D, (int)(elu != 0), g_n, g_s, scratch, rpb);
+  }
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, C, g_bias);
+  return done();
+}
+
 int csl_sage_cat_rows_bwd_f32(const int32_t* self_ids, const int32_t* owned, const int32_t* deg, int64_t n,
                               const float* gcat, int64_t ldg, float* gx, int64_t n_x, float* gagg, int64_t n_agg,
                               int32_t H, void* stream);
@@ -1124,6 +1231,12 @@ int64_t csl_gat_logits_bwd_scratch(int64_t n, int32_t H, int32_t D) {
 int csl_gat_logits_bwd_f32(const float* z, const float* attn_l, const float* attn_r, const float* g_el,
                            const float* g_er, int64_t n, int32_t H, int32_t D, float* g_z, float* g_attn_l,
                            float* g_attn_r, float* scratch, void* stream) {
+  return csl_gat_logits_bwd_acc_f32(z, attn_l, attn_r, g_el, g_er, n, H, D, g_z, 0, g_attn_l, g_attn_r, scratch, stream);
+}
+
+int csl_gat_logits_bwd_acc_f32(const float* z, const float* attn_l, const float* attn_r, const float* g_el,
+                               const float* g_er, int64_t n, int32_t H, int32_t D, float* g_z, int32_t accumulate,
+                               float* g_attn_l, float* g_attn_r, float* scratch, void* stream) {
   if (n < 0 || !g_attn_l || !g_attn_r || H < 1 || D < 4 || D % 4 != 0 || D > 256) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int C = H * D;
@@ -1134,7 +1247,7 @@ int csl_gat_logits_bwd_f32(const float* z, const float* attn_l, const float* att
         !aligned16(scratch))
       return CSL_E_INVALID;
     hipLaunchKernelGGL(k_gat_logits_bwd, dim3((unsigned)blocks), dim3(BLK), 0, st, z, attn_l, attn_r, g_el, g_er,
-                       (long long)n, (int)H, (int)D, g_z, scratch, scratch + blocks * C, rpb);
+                       (long long)n, (int)H, (int)D, g_z, scratch, scratch + blocks * C, rpb, (int)(accumulate != 0));
   }
   hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, C, g_attn_l);
   hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch + blocks * C, blocks, C,

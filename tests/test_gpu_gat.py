@@ -162,6 +162,43 @@ def _dense_gat_vectorised(model, trav, feats):
     return h
 
 
+@pytest.mark.parametrize("heads,hidden,B", [(8, 32, 256), (2, 12, 64), (3, 8, 700)])
+def test_fused_local_gat_layer_matches_the_node_by_node_path(mods, heads, hidden, B, monkeypatch):
+    """aggr.GatLayerLocal (a whole layer + ELU as one autograd node: epilogue kernels, one gradient buffer for z)
+    against the same model through the separate autograd nodes (CSLICER_NO_LOCAL_FUSE): logits, every parameter
+    gradient and the input gradient."""
+    abi, aggr, sg = mods
+    from cslicer import l0
+    torch.manual_seed(heads)
+    n, F0, classes = 6000, 20, 7
+    indptr, indices = l0.synth_graph(n, 12.0, seed=heads)
+    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(5, 4, 3), max_batch=B, mode=abi.MODE_GRAPH)
+    eng.submit_seeds([np.random.default_rng(3).permutation(n)[:B]])
+    slices = sg.slices_of(eng)
+    monkeypatch.setattr(sg, "ROW_PAD", 512)          # both the padded and the unpadded GEMM operand occur
+    model = sg.DistGATModel(F0, hidden, classes, heads=heads, n_layers=3).cuda()
+    with torch.no_grad():
+        for conv in model.convs:
+            conv.bias.normal_(0, 0.1)
+    x0 = torch.randn(slices[2][0].n_in, F0, device="cuda")
+    w = torch.randn(B, classes, device="cuda")
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(sg, "_NO_LOCAL_FUSE", not fused)
+        model.zero_grad()
+        x = x0.clone().requires_grad_()
+        out = model.forward_parts(slices, {0: x})[0]
+        assert (type(out.grad_fn).__name__ != "GatLayerLocalBackward") or fused
+        (out * w).sum().backward()
+        res.append((out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in model.parameters()]))
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-5, atol=1e-5)
+    scale = lambda t: max(1.0, float(t.abs().max()))                                                # noqa: E731
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-4 * scale(res[1][1]))
+    for a_, b_ in zip(res[0][2], res[1][2]):
+        torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-4 * scale(b_))
+    eng.close()
+
+
 def test_gat_config5_shape_eight_parts(mods):
     """BASELINE configs[4] shape: 3-layer GAT, 8 heads x 32, fanout 10/10/10, batch 1024, EIGHT parts (all in this
     process; products-like degrees on a 400k-node graph so that the dense reference fits), against the unsplit

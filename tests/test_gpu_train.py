@@ -271,5 +271,8 @@ def test_rccl_calls_on_one_gpu(kind):
     assert got[0] != "error", got[1]
     plain, ranked, overlapped = got
     assert p.exitcode == 0
-    np.testing.assert_allclose(ranked, plain, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(overlapped, plain, rtol=1e-5, atol=1e-6)   # side-stream exchange schedule (SAGE)
+    # GAT: the single-part path is the fused layer node (different summation orders in its reductions; gradients
+    # agree to 1e-4, tests/test_gpu_gat.py), and Adam turns noise-level gradient entries into lr-sized steps
+    tol = 1e-3 if kind == "gat" else 1e-5
+    np.testing.assert_allclose(ranked, plain, rtol=tol, atol=1e-6)
+    np.testing.assert_allclose(overlapped, plain, rtol=tol, atol=1e-6)   # side-stream exchange schedule (SAGE)
