@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--e2e-steps", type=int, default=128,
                     help="end-to-end training minibatches for the secondary iters/s figure (0 = skip)")
     ap.add_argument("--no-e2e-multi", action="store_true", help="several GPUs: skip the split-parallel training leg")
+    ap.add_argument("--no-e2e-dp", action="store_true",
+                    help="several GPUs: skip the data-parallel training leg (e2e.data_parallel)")
     ap.add_argument("--e2e-timeout", type=float, default=180.0, help="several GPUs: watchdog of the e2e leg, seconds")
     ap.add_argument("--e2e-multi", action="store_true", help="(default now; kept for older command lines)")
     ap.add_argument("--e2e-model", choices=("sage", "gat"), default="sage",
@@ -223,7 +225,7 @@ def self_launch(gpus, argv):
 E2E_FAILED_RC = 3
 
 
-def run_guarded(leg, out, rank, world, timeout, store=None):
+def run_guarded(leg, out, rank, world, timeout, store=None, partial=None):
     """Run the multi-rank e2e leg under a watchdog.  On success rank 0 gets the result in out["e2e"].  If the leg
     raises on some rank, or does not finish within `timeout` seconds (a collective some other rank never joined),
     rank 0 prints the line with `e2e.error` and every process exits with E2E_FAILED_RC -- never 0: the process
@@ -244,8 +246,10 @@ def run_guarded(leg, out, rank, world, timeout, store=None):
 
     def give_up(msg):
         if rank == 0:
-            out["e2e"] = {"error": msg}
-            out["e2e_iters_per_sec"] = None
+            # (`partial`: what the leg had finished before it failed -- the split-parallel figures survive a failure
+            # of the data-parallel leg that follows them)
+            out["e2e"] = dict(partial or {}, error=msg)
+            out["e2e_iters_per_sec"] = (partial or {}).get("iters_per_sec")
             sys.stdout.write(json.dumps(out) + "\n")
             sys.stdout.flush()
             store_do(lambda: store.set(k_ack, "1"))
@@ -549,6 +553,32 @@ def main():
             "scaling": "strong",
         }
 
+    # ---- the same step DATA-parallel (several GPUs only): every GPU holds graph + features, trains 1/N of each minibatch
+    # with the single-GPU native step, one gradient all-reduce per step (cslicer.train.DataParallelTrainer)
+    def e2e_dp_leg():
+        from cslicer.train import DataParallelTrainer, synthetic_node_data
+        feats = lambda own: synthetic_node_data(N, args.e2e_feat, args.e2e_classes, seed=0, rows=own)[0]  # noqa: E731
+        labels = lambda own: synthetic_node_data(N, 1, args.e2e_classes, seed=0, rows=own)[1]            # noqa: E731
+        tr = DataParallelTrainer(indptr, indices, feats, labels, args.e2e_classes, rank, world, dist, batch=B,
+                                 fanouts=fan, streams=args.e2e_streams, hidden=args.e2e_hidden, device=device,
+                                 feat_dim=args.e2e_feat)
+        tr.set_nodes(perm)
+        tr.run(48)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.run(args.e2e_steps, first_batch=48)
+        torch.cuda.synchronize()
+        barrier()
+        t_dp = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)
+        tr.close()
+        return {"iters_per_sec": args.e2e_steps / t_dp, "ms_per_iter": 1e3 * t_dp / args.e2e_steps,
+                "steps": args.e2e_steps, "scaling": "strong",
+                "config": "data-parallel GraphSAGE fanout %s, batch %d (global; %d seeds per GPU), %d GPU(s), whole graph + "
+                          "feature table on every GPU, native step + one gradient all-reduce per step; features %d, "
+                          "hidden %d, classes %d, fp32, Adam" % ("/".join(map(str, fan)), B, (B + world - 1) // world,
+                                                                 world, args.e2e_feat, args.e2e_hidden, args.e2e_classes)}
+
     if rank == 0:
         # ---- per-kernel HIP-event timing pass (engine's own stream) for the roofline
         if not args.no_kernel_timing:
@@ -687,7 +717,15 @@ def main():
         if world == 1:
             out["e2e"] = e2e_leg()
         else:
-            run_guarded(e2e_leg, out, rank, world, args.e2e_timeout, default_store(dist))
+            partial = {}
+
+            def both_legs():
+                res = e2e_leg()                      # split-parallel: the reference's design (north_star)
+                partial.update(res)
+                if not args.no_e2e_dp and args.e2e_model == "sage":
+                    res["data_parallel"] = e2e_dp_leg()
+                return res
+            run_guarded(both_legs, out, rank, world, args.e2e_timeout, default_store(dist), partial)
     finish(out, rank, dist)
 
 

@@ -95,7 +95,7 @@ class Trainer(object):
         self.opt = aggr.Adam(list(self.model.parameters()), lr=lr)
         # the fused single-GPU GraphSAGE step as one native call per minibatch (CSLICER_PY_STEP=1: the same kernels
         # issued from Python through an autograd node, A/B switch and what the tests compare it with)
-        self.native = None
+        self.native, self.grad_sync = None, None
         if (by_source and F % 4 == 0 and hidden % 4 == 0 and not os.environ.get("CSLICER_PY_STEP")
                 and not splitgnn._NO_LOCAL_FUSE):
             self.native = aggr.SageStep(self.model, splitgnn.ROW_PAD, splitgnn.SPLIT_K)
@@ -136,7 +136,9 @@ class Trainer(object):
             loss = self._loss_ring[self._ring_at:self._ring_at + 1]    # (run() sized the ring for its steps)
             self._ring_at += 1
             self.native([slices[self.L - 1 - k][self.rank] for k in range(self.L)], self.feat, self.labels,
-                        1.0 / max(n_seeds, 1), loss)
+                        1.0 / self._loss_den(stream, slot, n_seeds), loss)
+            if self.grad_sync is not None:
+                self.grad_sync(self.native.grads)         # (data-parallel: sum over the ranks' shares of the minibatch)
             self.opt.step(flat_grads=self.native.grads)
             _roctx.pop()
             self.steps_done += 1
@@ -215,7 +217,7 @@ class Trainer(object):
             ev = done[r % self.SLOTS]
             if ev is not None:
                 ev.synchronize()                          # the slot's previous consumer has finished
-            self.eng.submit_round(plan[r][0], self.B, plan[r][1], slot=r % self.SLOTS)
+            self._submit(plan[r][0], plan[r][1], r % self.SLOTS)
 
         submit(0)
         for r in range(len(plan)):
@@ -228,6 +230,14 @@ class Trainer(object):
             done[r % self.SLOTS] = ev
         torch.cuda.synchronize()
         return [float(x) for x in losses]
+
+    def _submit(self, first, n, slot):
+        """minibatches [first, first + n) of the node order into result slot `slot`"""
+        self.eng.submit_round(first, self.B, n, slot=slot)
+
+    def _loss_den(self, stream, slot, n_seeds):
+        """what the summed loss of this rank's seeds is divided by: the minibatch's seed count"""
+        return max(n_seeds, 1)
 
     def reset_units(self):
         for u in self.units:
@@ -261,6 +271,45 @@ class Trainer(object):
 
     def close(self):
         self.eng.close()
+
+
+class DataParallelTrainer(Trainer):
+    """The same model trained DATA-parallel: every GPU holds the whole graph and feature table (288 GB of HBM per
+    MI355X: ogbn-products is 1.5 GB, papers100M 64 GB), samples and trains its 1/W share of every minibatch with the
+    single-GPU native step, and one all-reduce (RCCL) sums the 0.7 MB of gradients.  Not the reference's design -- its
+    trainer is split-parallel (python/train.py, `Trainer` above with world > 1) -- but what the same slicer + step give
+    when a GPU is large enough to hold everything: no per-layer boundary exchange, the only collective is the gradient
+    all-reduce.  A minibatch of B seeds is dealt in contiguous chunks of ceil(B / W); the loss is the sum over a
+    rank's seeds / B, so the reduced gradient is the whole minibatch's (each chunk samples its own neighbourhoods)."""
+
+    def __init__(self, indptr, indices, features, labels, n_classes, dp_rank, dp_world, dist, batch=1024, **kw):
+        self.dp_rank, self.dp_world, self.dp_dist, self.global_B = int(dp_rank), int(dp_world), dist, int(batch)
+        self.chunk = (self.global_B + self.dp_world - 1) // self.dp_world
+        super().__init__(indptr, indices, features, labels, n_classes, rank=0, world=1, batch=self.chunk, dist=None,
+                         rank_path=False, **kw)
+        if self.native is None:
+            raise ValueError("the data-parallel trainer runs the native GraphSAGE step (feature and hidden widths "
+                             "multiples of 4, at least two layers)")
+        if self.dp_world > 1:
+            self.grad_sync = lambda flat: self.dp_dist.all_reduce(flat)
+        self._den = {}
+
+    def set_nodes(self, nodes):
+        self.nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        self.n_batches = (len(self.nodes) + self.global_B - 1) // self.global_B
+
+    def _submit(self, first, n, slot):
+        mine = []
+        for j in range(n):
+            lo = (first + j) * self.global_B
+            hi = min(lo + self.global_B, len(self.nodes))
+            a = min(lo + self.dp_rank * self.chunk, hi)
+            mine.append(self.nodes[a:min(a + self.chunk, hi)])
+            self._den[(j, slot)] = max(hi - lo, 1)
+        self.eng.submit_seeds(mine, slot=slot)
+
+    def _loss_den(self, stream, slot, n_seeds):
+        return self._den[(stream, slot)]
 
 
 TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")

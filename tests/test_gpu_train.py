@@ -56,6 +56,75 @@ def test_native_step_trains_like_the_python_step(monkeypatch):
     np.testing.assert_allclose(curves[0], curves[1], rtol=2e-3)
 
 
+def _dp_rank_main(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "occ-gnn_amd"))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cslicer.train import DataParallelTrainer
+        from test_gpu_train import _task
+        indptr, indices, feats, labels, perm = _task()
+        # batch 250 over 3 ranks: chunks of 84 / 84 / 82; the epoch's last minibatch is short
+        t = DataParallelTrainer(indptr, indices, feats, labels, 5, rank, world, dist, batch=250, fanouts=(10, 5),
+                                streams=3, hidden=16, lr=1e-2, seed=3)
+        t.set_nodes(perm[:250 * 7 + 100 * (world > 2)])
+        losses = t.run(12)
+        tl = torch.tensor(losses, dtype=torch.float64)
+        dist.all_reduce(tl)     # a minibatch's loss = sum of the ranks' shares (each already divided by its seed count)
+        w = torch.cat([p.detach().reshape(-1).cpu() for p in t.model.parameters()])
+        t.close()
+        dist.barrier()
+        q.put((rank, tl.tolist(), w.numpy()))
+        dist.destroy_process_group()
+    except Exception as ex:
+        q.put((rank, "error: " + repr(ex), None))
+        raise
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_data_parallel_ranks_stay_identical_and_learn(world):
+    """DataParallelTrainer: every rank trains its chunk of each minibatch with the native step, gradients are summed
+    by one all-reduce (gloo here, two / three processes on the one GPU): the replicas' weights stay bit-identical and
+    the loss falls."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    for g in got:
+        assert not isinstance(g[1], str), g[1]
+    for g in got[1:]:
+        np.testing.assert_array_equal(g[2], got[0][2])
+        np.testing.assert_allclose(g[1], got[0][1])
+    losses = got[0][1]
+    assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < 0.85 * np.mean(losses[:3]), losses
+
+
+def test_data_parallel_world_of_one_is_the_single_gpu_trainer():
+    """dp_world = 1: seeds handed over as lists instead of ranges of the uploaded node order, nothing else differs."""
+    from cslicer.train import DataParallelTrainer, Trainer
+    indptr, indices, feats, labels, perm = _task()
+    kw = dict(fanouts=(10, 5), streams=4, hidden=32, lr=1e-2, seed=7)
+    a = Trainer(indptr, indices, feats, labels, 5, rank=0, world=1, batch=256, **kw)
+    b = DataParallelTrainer(indptr, indices, feats, labels, 5, 0, 1, None, batch=256, **kw)
+    for t in (a, b):
+        t.set_nodes(perm)
+    la, lb = a.run(10), b.run(10)
+    np.testing.assert_array_equal(la, lb)
+    a.close()
+    b.close()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
