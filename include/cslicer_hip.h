@@ -56,7 +56,9 @@ enum {
                                  every occurrence is sampled, the lists are merged as bipartite.cpp:3-17 does */
   CSL_ERR_SEED_RANGE = 4,     /* seed id outside [0, num_nodes) */
   CSL_ERR_FRONTIER_CAP = 8,   /* a frontier outgrew its configured capacity */
-  CSL_ERR_BUCKET_FULL = 16    /* an LDS dedup bucket overflowed (hash skew) */
+  CSL_ERR_BUCKET_FULL = 16    /* an LDS dedup table overflowed: since round 2 only for ids that collide under BOTH the
+                                 bucket hash and the pass hash of an oversized bucket (k_bucket resolves a bucket with
+                                 more entries than table slots in several passes) */
 };
 
 /* list kinds: members of BiPartite (bipartite.h:9-26) */

@@ -256,6 +256,12 @@ __device__ __forceinline__ unsigned long long lt_mask() {
 __device__ __forceinline__ uint32_t bucket_of(uint32_t v, uint32_t nb) {
   return __umulhi(v * 0x9E3779B1u, nb);
 }
+// which pass of an oversized bucket resolves an id (k_bucket): a third mix of the id
+__device__ __forceinline__ uint32_t pass_of(uint32_t v, uint32_t npass) {
+  uint32_t x = v * 0x27D4EB2Fu;
+  x ^= x >> 13;
+  return __umulhi(x * 0x165667B1u, npass);
+}
 // slot inside a bucket's LDS table: independent mix of the same id
 __device__ __forceinline__ uint32_t slot_of(uint32_t v) {
   uint32_t x = v * 0x85EBCA6Bu;
@@ -1033,7 +1039,7 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
       en[r] = qs[ok ? q1 + k : 0u];
       if (!ok) en[r] = make_uint2(UNSET, 0u);
     }
-    {
+    auto clear_table = [&]() {
       // 16-byte LDS stores: 6 per thread instead of 24
       const uint4 u4 = make_uint4(UNSET, UNSET, UNSET, UNSET);
       for (uint32_t i = n; i < (uint32_t)HCAP / 4; i += BT) {
@@ -1041,7 +1047,31 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
         reinterpret_cast<uint4*>(h_epos)[i] = u4;
         reinterpret_cast<uint4*>(h_self)[i] = u4;
       }
-    }
+    };
+    if (cnt > (uint32_t)HCAP) {  // block-uniform
+      // More entries than table slots: the bucket's ids MIGHT not fit (it takes ids chosen against the bucket hash:
+      // for hashed ids a bucket of twice the mean is a 45-sigma event).  Resolved in several passes over the queue,
+      // each taking the ids of one class of an independent hash, so the sample stays exact instead of being
+      // flagged CSL_ERR_BUCKET_FULL; only ids that also collide under the second hash can still overflow a pass.
+      const uint32_t npass = (cnt + (uint32_t)HCAP / 2 - 1) / ((uint32_t)HCAP / 2);
+      for (uint32_t pass = 0; pass < npass; pass++) {
+        clear_table();
+        __syncthreads();
+        for (uint32_t k = n; k < cnt; k += BT) {
+          const uint2 ee = q[k];
+          if (pass_of(ee.x, npass) == pass) insert(ee);
+        }
+        __syncthreads();
+        for (uint32_t k = n; k < cnt; k += BT) {
+          const uint2 ee = q[k];
+          if (pass_of(ee.x, npass) != pass) continue;
+          const uint32_t h = ht_find(h_key, ee.x);
+          if (h != UNSET) evaluate(ee, h);
+        }
+        __syncthreads();
+      }
+    } else {
+    clear_table();
     __syncthreads();
     // (one entry after the other: probing all four register entries together, reads then the CAS of the empty
     // slots, was measured slower twice -- 204 us in round 1, 215 us in round 2 against 158 -- and probing with the
@@ -1069,6 +1099,7 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
       const uint2 ee = q[k];
       const uint32_t h = ht_find(h_key, ee.x);
       if (h != UNSET) evaluate(ee, h);  // UNSET: table overflow, already flagged
+    }
     }
     if (!more) break;
     __syncthreads();  // the table is rebuilt for the next bucket

@@ -296,3 +296,33 @@ def test_both_row_lookup_tables(abi, orc, monkeypatch):
         e.submit_seeds([perm[:200]])
         assert_same_sample(e.sample_dict(0), want, what="row lookup table, 64-bit=%s" % force64)
         e.close()
+
+
+def test_ids_chosen_against_the_bucket_hash_still_slice_exactly(abi, orc):
+    """DuplicateRemover under adversarial ids: every sampled neighbour comes from a set of ~8 k node ids that the
+    dedup kernel's bucket hash (umulhi(v * 0x9E3779B1, nb)) sends to bucket 0 whatever the bucket count, so one
+    bucket receives ALL edge candidates of a layer -- ~10 k entries with ~5.8 k distinct ids in layer 0, ~70 k entries
+    in layer 1 -- against an LDS table of 4096 slots.  Round 1 flagged such a sample CSL_ERR_BUCKET_FULL; k_bucket
+    now resolves an oversized bucket in passes over a second hash of the ids: bit-exact against the oracle."""
+    n = 1 << 21
+    inv = pow(0x9E3779B1, -1, 1 << 32)
+    t = np.arange(1 << 24, dtype=np.uint64)
+    v = (t * np.uint64(inv)) & np.uint64(0xFFFFFFFF)
+    target = np.sort(v[v < n].astype(np.int64))            # hashed value < 2^24: bucket 0 for any nb <= 256
+    assert 7000 < len(target) < 9500
+    assert int(((target.astype(np.uint64) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)).max()) < (1 << 24)
+    rng = np.random.default_rng(5)
+    deg = 16
+    indptr = np.arange(n + 1, dtype=np.int64) * deg
+    indices = np.sort(target[rng.integers(0, len(target), size=(n, deg))], axis=1).reshape(-1)
+    seeds = rng.permutation(n)[:1024]
+    e = abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 10), max_batch=1024, flags=abi.FLAG_KEEP_CANDIDATES)
+    o = orc.Oracle(indptr, indices, n_parts=4, fanouts=(10, 10))
+    for b in range(2):                                      # two consecutive minibatches: rng position carries over
+        sd = seeds if b == 0 else rng.permutation(n)[:1000]
+        e.submit_seeds([sd])
+        got, want = e.sample_dict(0), o.sample(sd)          # (sample_dict raises on any device error bit)
+        assert_same_sample(got, want, what="adversarial ids, batch %d" % b)
+        distinct = len(np.unique(np.concatenate(want["nbr_flat"])))
+        assert distinct > 4096, distinct                    # more distinct ids in that one bucket than table slots
+    e.close()
