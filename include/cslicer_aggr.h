@@ -150,7 +150,8 @@ int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, co
 
 /* out[r, :] = (y == NULL || y[r, :] > 0) ? g[r, :] : 0 for r < n, zero rows for n <= r < n_pad;
  * colsum[c] = sum_r out[r, c]: ReLU backward + row padding of the GEMM operand + bias gradient in one pass
- * (two-stage reduction, no atomics, nothing to pre-zero).  scratch: csl_relu_bwd_colsum_scratch(n_pad, H) floats. */
+ * (two-stage reduction, no atomics, nothing to pre-zero).  scratch: csl_relu_bwd_colsum_scratch(n_pad, H) floats =
+ * [blocks][H] per-block sums; colsum == NULL leaves them there for the caller's own second stage (csl_reduce_multi_f32). */
 int64_t csl_relu_bwd_colsum_scratch(int64_t n_pad, int32_t H);
 int csl_relu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t n, int64_t n_pad,
                             float* out, int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream);
@@ -240,6 +241,44 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
                          const int32_t* seed_ids, const int64_t* labels, float scale, int64_t row_pad, int32_t n_slabs,
                          float* grads, float* loss, float* workspace, int64_t workspace_floats, void* stream);
 const char* csl_sage_last_error(void);
+
+/* ---- one rank of the SPLIT-PARALLEL training step (python/train.py + dist_sageconv.py:42-84 on several GPUs) ----
+ * Part g of P, one process per part: forward, loss over the seeds this part owns and backward of the GraphSAGE model
+ * for one minibatch as one call.  Per layer the partial sums of the out rows that PEERS own are sent to their owners
+ * and the partials of the rows this part owns are received and merged (pull_for_remotes / push_from_remotes,
+ * dist_sageconv.py:52-65); backward runs the reverse exchange.  The exchange is the caller's: `exchange(user, layer,
+ * backward, src, dst, width, stream)` must move row blocks of `width` floats between the parts --
+ *   forward  (backward = 0): src = [n_from, width] rows grouped by owner (send_counts), dst = [n_to, width] rows grouped
+ *                            by sender (recv_counts);
+ *   backward (backward = 1): the reverse: src = [n_to, width] (recv_counts), dst = [n_from, width] (send_counts)
+ * -- ordered on `stream` (an all_to_all_single over RCCL in production), and return 0 or a negative code.
+ * slices[k] (model order, deepest first): the graph-mode slice of part g (csl_config.part_mask), device pointers;
+ * from_all / to_all: the per-peer boundary lists back to back; n_in of layer k = n_owned of layer k-1.
+ * feat: this part's resident feature rows, read through feat_rows[n_in of layer 0] (local row of every in node);
+ * seed_ids [n_owned of the top layer]: global ids of the owned seeds, label of a seed = labels[label_rows ?
+ * label_rows[id] : id]; scale = 1 / (seeds of the WHOLE minibatch).  grads: W_0, b_0, ... of THIS part's share (the
+ * caller all-reduces them); *loss: this part's share.  Widths multiples of 4, at most 256 classes.
+ * workspace: csl_sage_rank_workspace(...) floats. */
+typedef struct {
+  const int32_t* indptr;
+  const int32_t* indices;
+  const int32_t* self_ids_in;
+  const int32_t* owned_out_nodes;
+  const int32_t* owned_degree;
+  const int32_t* from_all;
+  const int32_t* to_all;
+  int64_t n_out, n_in, n_owned, n_from, n_to;
+} csl_sage_rank_slice;
+typedef int (*csl_exchange_fn)(void* user, int32_t layer, int32_t backward, const float* src, float* dst, int32_t width,
+                               void* stream);
+int64_t csl_sage_rank_workspace(int32_t n_layers, const int32_t* dims, const csl_sage_rank_slice* slices, int64_t row_pad,
+                                int32_t n_slabs);
+int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_rank_slice* slices,
+                              const float* const* weights, const float* const* biases, const float* feat, int64_t ldf,
+                              const int32_t* feat_rows, const int32_t* seed_ids, const int32_t* label_rows,
+                              const int64_t* labels, float scale, int64_t row_pad, int32_t n_slabs,
+                              csl_exchange_fn exchange, void* user, float* grads, float* loss, float* workspace,
+                              int64_t workspace_floats, void* stream);
 
 #ifdef __cplusplus
 }

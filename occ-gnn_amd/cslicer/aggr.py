@@ -21,7 +21,7 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_sage_cat_bwd_t_f32", "csl_sage_cat_bwd_t_scratch", "csl_gemm_f32", "csl_gemm_last_error",
            "csl_sum_slabs_f32", "csl_sage_fwd_bwd_f32", "csl_sage_fwd_bwd_workspace", "csl_sage_last_error",
            "csl_gemm_save_plans", "csl_gemm_load_plans", "csl_softmax_ce_partial_f32", "csl_reduce_multi_f32",
-           "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch"]
+           "csl_sage_rank_fwd_bwd_f32", "csl_sage_rank_workspace", "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch"]
 _ready = False
 
 
@@ -65,6 +65,10 @@ def _lib():
         L.csl_sage_fwd_bwd_f32.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, f32, i64, i32, vp, vp, vp, i64, vp]
         L.csl_sage_last_error.restype = C.c_char_p
         L.csl_gemm_save_plans.argtypes = [C.c_char_p]
+        L.csl_sage_rank_workspace.argtypes = [i32, vp, vp, i64, i32]
+        L.csl_sage_rank_workspace.restype = i64
+        L.csl_sage_rank_fwd_bwd_f32.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, f32, i64, i32, EXCHANGE_FN, vp,
+                                                vp, vp, vp, i64, vp]
         L.csl_gat_logits_bwd_acc_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp]
         L.csl_gat_finish_fwd_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
         L.csl_gat_finish_bwd_f32.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]
@@ -372,6 +376,86 @@ class SageStep(object):
                                     loss_out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), _stream())
         if rc < 0:
             raise _abi.CslError(rc, "csl_sage_fwd_bwd_f32: " + L.csl_sage_last_error().decode() + " / " +
+                                L.csl_gemm_last_error().decode())
+
+
+class SageRankSlice(C.Structure):
+    """csl_sage_rank_slice (cslicer_aggr.h)"""
+    _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("self_ids_in", C.c_void_p),
+                ("owned_out_nodes", C.c_void_p), ("owned_degree", C.c_void_p), ("from_all", C.c_void_p),
+                ("to_all", C.c_void_p), ("n_out", C.c_int64), ("n_in", C.c_int64), ("n_owned", C.c_int64),
+                ("n_from", C.c_int64), ("n_to", C.c_int64)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+
+
+class SageRankStep(object):
+    """One rank's forward + loss + backward of the SPLIT-parallel GraphSAGE step as one native call
+    (csl_sage_rank_fwd_bwd_f32); the 2 L - 1 boundary exchanges come back as callbacks and go through `comm`
+    (splitgnn.DistComm: all_to_all_single over RCCL, gloo in the tests).  Gradients of this rank's share land in
+    `self.grads` (W_0, b_0, ...) for the caller's all-reduce and aggr.Adam.step(flat_grads=...)."""
+
+    def __init__(self, model, row_pad, n_slabs, comm):
+        ws, bs = [c.fc.weight for c in model.convs], [c.fc.bias for c in model.convs]
+        self.L = len(ws)
+        self.dims = [ws[0].shape[1] // 2] + [w.shape[0] for w in ws]
+        self._params = ws + bs
+        self._dims = (C.c_int32 * (self.L + 1))(*self.dims)
+        self._w = (C.c_void_p * self.L)(*[w.data_ptr() for w in ws])
+        self._b = (C.c_void_p * self.L)(*[b.data_ptr() for b in bs])
+        self._sl = (SageRankSlice * self.L)()
+        self.row_pad, self.n_slabs, self.comm = int(row_pad), int(n_slabs), comm
+        n_grad = sum(w.numel() + b.numel() for w, b in zip(ws, bs))
+        self.grads = torch.empty((n_grad,), dtype=torch.float32, device=ws[0].device)
+        self._ws = None
+        self._cur = None
+        self._exc = None
+        self._cb = EXCHANGE_FN(self._exchange)     # (kept alive: the native call holds only the raw pointer)
+        gemm_load_plans()
+
+    def _view(self, ptr, rows, width):
+        off = (int(ptr or 0) - self._ws.data_ptr()) // 4 if rows else 0
+        return self._ws[off:off + rows * width].view(rows, width)
+
+    def _exchange(self, user, layer, backward, src, dst, width, stream):
+        try:
+            s = self._cur[layer]
+            send, recv = (s.to_counts, s.from_counts) if backward else (s.from_counts, s.to_counts)
+            self.comm.exchange_into(self._view(dst, sum(recv), width), self._view(src, sum(send), width), send, recv)
+            return 0
+        except Exception as ex:      # an exception cannot cross the C frame: reported after the native call returns
+            self._exc = ex
+            return -1
+
+    def __call__(self, slices, feat, feat_rows, seed_ids, label_rows, labels, scale, loss_out):
+        """slices: this part's `splitgnn.Slice`s in MODEL order; feat: the rank's resident feature rows; feat_rows
+        int32 [n_in of the deepest slice]: their local rows; seed_ids int32: global ids of the owned seeds."""
+        A = _abi
+        for k, s in enumerate(slices):
+            c = self._sl[k]
+            c.indptr, c.indices, c.self_ids_in = s.ptr(A.INDPTR), s.ptr(A.INDICES), s.ptr(A.SELF_IDS_IN)
+            c.owned_out_nodes, c.owned_degree = s.ptr(A.OWNED_OUT_NODES), s.ptr(A.OWNED_DEGREE)
+            c.from_all, c.to_all = s.ptr(A.FROM_IDS), s.ptr(A.TO_IDS)
+            c.n_out, c.n_in, c.n_owned = s.n_out, s.n_in, s.n_owned
+            c.n_from, c.n_to = sum(s.from_counts), sum(s.to_counts)
+        L = _lib()
+        need = L.csl_sage_rank_workspace(self.L, self._dims, self._sl, self.row_pad, self.n_slabs)
+        if need < 0:
+            raise _abi.CslError(need, "csl_sage_rank_workspace: unsupported model or slices")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((int(need * 1.25) + 1024,), dtype=torch.float32, device=feat.device)
+        self._cur, self._exc = slices, None
+        rc = L.csl_sage_rank_fwd_bwd_f32(self.L, self._dims, self._sl, self._w, self._b, feat.data_ptr(), feat.stride(0),
+                                         _p(feat_rows), _p(seed_ids), _p(label_rows) if label_rows is not None else None,
+                                         labels.data_ptr(), float(scale), self.row_pad, self.n_slabs, self._cb, None,
+                                         self.grads.data_ptr(), loss_out.data_ptr(), self._ws.data_ptr(),
+                                         self._ws.numel(), _stream())
+        self._cur = None
+        if self._exc is not None:
+            raise self._exc
+        if rc < 0:
+            raise _abi.CslError(rc, "csl_sage_rank_fwd_bwd_f32: " + L.csl_sage_last_error().decode() + " / " +
                                 L.csl_gemm_last_error().decode())
 
 

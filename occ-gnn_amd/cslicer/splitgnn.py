@@ -58,7 +58,8 @@ class Slice(object):
     t_indptr / t_indices: the slice by source (engine flag FLAG_TRANSPOSE; empty otherwise and for the deepest layer).
     from_all / to_all: the per-peer lists back to back (receiver / sender order, the own one empty)."""
 
-    __slots__ = ("part", "n_parts", "n_in", "n_out", "n_owned", "n_edges", "_t", "_origin", "_lbase", "_lm") + \
+    __slots__ = ("part", "n_parts", "n_in", "n_out", "n_owned", "n_edges", "from_counts", "to_counts",
+                 "_t", "_origin", "_lbase", "_lm") + \
         tuple(_SLICE_LISTS) + ("from_ids", "to_ids")
 
     def _seg(self, kind, lo, hi):
@@ -129,6 +130,9 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
             s.n_out = int(lm.off[_abi.OUT_NODES][g + 1]) - int(lm.off[_abi.OUT_NODES][g])
             s.n_owned = int(lm.off[_abi.OWNED_OUT_NODES][g + 1]) - int(lm.off[_abi.OWNED_OUT_NODES][g])
             s.n_edges = int(lm.off[_abi.INDICES][g + 1]) - int(lm.off[_abi.INDICES][g])
+            # rows per peer of the boundary lists (from_ids[p] / to_ids[p]; the own entry is empty)
+            s.from_counts = [int(lm.pair_off[0][g][p + 1]) - int(lm.pair_off[0][g][p]) for p in range(P)]
+            s.to_counts = [int(lm.pair_off[1][g][p + 1]) - int(lm.pair_off[1][g][p]) for p in range(P)]
             row[g] = s
         out.append(row)
     return out
@@ -697,6 +701,18 @@ class DistComm(object):
     def _exchange(self, send_cat, send_counts, recv_counts):
         with _roctx.range("exchange"):
             return self._exchange_impl(send_cat, send_counts, recv_counts)
+
+    def exchange_into(self, out, send_cat, send_counts, recv_counts):
+        """the same exchange into a caller-owned [sum(recv_counts), H] tensor (the native rank step's workspace)"""
+        if self.dist.get_backend(self.group) == "gloo" and send_cat.is_cuda:
+            host = torch.empty(tuple(out.shape), dtype=send_cat.dtype)
+            self.dist.all_to_all_single(host, send_cat.cpu(), output_split_sizes=list(recv_counts),
+                                        input_split_sizes=list(send_counts), group=self.group)
+            out.copy_(host)
+            return out
+        self.dist.all_to_all_single(out, send_cat, output_split_sizes=list(recv_counts),
+                                    input_split_sizes=list(send_counts), group=self.group)
+        return out
 
     def _exchange_impl(self, send_cat, send_counts, recv_counts):
         H = send_cat.shape[1]

@@ -102,6 +102,13 @@ class Trainer(object):
             self._loss_ring, self._ring_at = torch.zeros((4096,), dtype=torch.float32, device=self.dev), 0
         self.comm = splitgnn.DistComm(device=self.dev) if self.rank_path else None
         self.overlap = overlap
+        # one process per part: the same idea -- everything between two boundary exchanges is issued by one native call,
+        # the exchanges come back as callbacks into self.comm (CSLICER_PY_STEP=1 / overlap=True: the autograd path)
+        self.native_rank = None
+        if (self.rank_path and model == "sage" and F % 4 == 0 and hidden % 4 == 0 and n_classes <= 256 and not overlap
+                and not os.environ.get("CSLICER_PY_STEP")):
+            self.native_rank = aggr.SageRankStep(self.model, splitgnn.ROW_PAD, splitgnn.SPLIT_K, self.comm)
+            self._loss_ring, self._ring_at = torch.zeros((4096,), dtype=torch.float32, device=self.dev), 0
         self.t_forward = self.t_slice = 0.0
         self.steps_done = 0
         # units of the steps done (measurement only): per model layer k the output rows, source rows and edges
@@ -130,6 +137,19 @@ class Trainer(object):
         n_seeds = int(meta.n_seeds)
         fused = (not self.rank_path and self.kind == "sage" and self.P == 1 and self.feat.shape[1] % 4 == 0
                  and not splitgnn._NO_LOCAL_FUSE)
+        if self.native_rank is not None:
+            _roctx.push("step_native_rank")
+            loss = self._loss_ring[self._ring_at:self._ring_at + 1]
+            self._ring_at += 1
+            rows = deep.in_nodes if self.local_row is None else self.local_row[deep.in_nodes.long()]
+            seeds = top.out_nodes[top.owned_out_nodes.long()]          # the seeds this rank owns, frontier order
+            self.native_rank([slices[self.L - 1 - k][self.rank] for k in range(self.L)], self.feat, rows, seeds,
+                             self.local_row, self.labels, 1.0 / max(n_seeds, 1), loss)
+            self.dist.all_reduce(self.native_rank.grads)               # replicated weights: sum of the ranks' shares
+            self.opt.step(flat_grads=self.native_rank.grads)
+            _roctx.pop()
+            self.steps_done += 1
+            return loss
         if self.native is not None:
             # forward, loss, backward: one native call; the optimizer: a second one on the flat gradient buffer
             _roctx.push("step_native")
@@ -207,7 +227,7 @@ class Trainer(object):
         if not plan:
             return losses
 
-        if self.native is not None:
+        if self.native is not None or self.native_rank is not None:
             if self._loss_ring.numel() < n_steps:
                 self._loss_ring = torch.zeros((n_steps,), dtype=torch.float32, device=self.dev)
             self._ring_at = 0

@@ -1115,7 +1115,7 @@ int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, co
 
 int csl_relu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t n, int64_t n_pad,
                             float* out, int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream) {
-  if (n < 0 || n_pad < n || H < 1 || !colsum) return CSL_E_INVALID;
+  if (n < 0 || n_pad < n || H < 1) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const long long rpb = rb_rows(n_pad);
   const long long blocks = (n_pad + rpb - 1) / rpb;
@@ -1136,7 +1136,8 @@ int csl_relu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t
     }
 #undef LAUNCH_RBC
   }
-  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((H + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, (int)H, colsum);
+  // colsum == NULL: the per-block sums stay in scratch[blocks][H] for the caller's own second stage
+  if (colsum) hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((H + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, (int)H, colsum);
   return done();
 }
 

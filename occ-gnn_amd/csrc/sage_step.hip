@@ -212,3 +212,185 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
 }
 
 }  // extern "C"
+
+// ===== one rank of the SPLIT-PARALLEL step (python/train.py + dist_sageconv.py:42-84 with several GPUs) =============
+// The same sequencing for part g of P: per layer the partial sums of the boundary rows go to their owners and come
+// back merged (pull_for_remotes / push_from_remotes, dist_sageconv.py:52-65), backward mirrors it.  The exchange itself
+// is the CALLER's (a callback: torch.distributed's all_to_all_single over RCCL, or gloo in the tests) -- this file has no
+// communicator; everything between two exchanges is issued from here, so a step costs the host the 2 L callbacks plus
+// ~0.25 ms instead of ~1.2 ms of interpreter + autograd work, which is what bounds a rank once the GPU work is split N ways.
+namespace {
+
+struct RankLayout {
+  int64_t x0, send[CSL_MAX_LAYERS], recv[CSL_MAX_LAYERS], agg[CSL_MAX_LAYERS], cat[CSL_MAX_LAYERS], y[CSL_MAX_LAYERS],
+      gy[CSL_MAX_LAYERS], gcat[CSL_MAX_LAYERS], gx[CSL_MAX_LAYERS], slabs[CSL_MAX_LAYERS], bpart[CSL_MAX_LAYERS],
+      bblocks[CSL_MAX_LAYERS], mp[CSL_MAX_LAYERS];
+  bool slabbed[CSL_MAX_LAYERS];
+  int64_t lpart, lblocks, total;
+};
+
+bool rank_lay_out(int32_t L, const int32_t* dims, const csl_sage_rank_slice* sl, int64_t row_pad, int32_t n_slabs,
+                  RankLayout& o) {
+  if (L < 1 || L > CSL_MAX_LAYERS || n_slabs < 1) return false;
+  int64_t at = 0;
+  o.x0 = at, at += up4(sl[0].n_in * (int64_t)dims[0]);
+  for (int k = 0; k < L; k++) {
+    const int64_t in = dims[k], out = dims[k + 1];
+    const csl_sage_rank_slice& s = sl[k];
+    if (in < 4 || in % 4 != 0 || out < 1 || (k + 1 < L && out % 4 != 0)) return false;
+    if (s.n_out < 0 || s.n_in < 0 || s.n_owned < 0 || s.n_from < 0 || s.n_to < 0 || s.n_owned > s.n_out) return false;
+    if (k > 0 && s.n_in != sl[k - 1].n_owned) return false;  // a layer's sources are the nodes this part owns below
+    const int64_t mp = pad_rows(s.n_owned, row_pad);
+    o.mp[k] = mp;
+    o.send[k] = at, at += up4(s.n_from * in);   // forward: partial sums of peer-owned rows; backward: their gradients back
+    o.recv[k] = at, at += up4(s.n_to * in);     // forward: partials received for owned rows; backward: their gradients
+    o.agg[k] = at, at += up4(s.n_out * in);     // forward: merged sums (owned rows); backward: their gradient
+    o.cat[k] = at, at += up4(mp * 2 * in);
+    o.y[k] = at, at += up4(mp * out);
+    o.gy[k] = at, at += up4(mp * out);
+    o.gcat[k] = at, at += up4(mp * 2 * in);
+    o.gx[k] = at, at += k > 0 ? up4(s.n_in * in) : 0;
+    const int64_t wn = out * 2 * in;
+    o.slabbed[k] = row_pad > 0 && mp >= row_pad && n_slabs > 1 && mp % n_slabs == 0 && wn % 4 == 0;
+    o.slabs[k] = at, at += o.slabbed[k] ? up4(wn * n_slabs) : 0;
+    const int64_t part = k + 1 < L ? csl_relu_bwd_colsum_scratch(mp, (int32_t)out) : 0;
+    o.bblocks[k] = part / out;
+    o.bpart[k] = at, at += up4(part);
+  }
+  const int64_t C = dims[L];
+  if (C > 256) return false;  // (the loss pass leaves the bias column sums: csl_softmax_ce_partial_f32)
+  o.lblocks = (o.mp[L - 1] + 3) / 4;
+  o.lpart = at, at += up4(o.lblocks);
+  o.bblocks[L - 1] = o.lblocks;
+  o.bpart[L - 1] = at, at += up4(o.lblocks * C);
+  o.total = at;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t csl_sage_rank_workspace(int32_t n_layers, const int32_t* dims, const csl_sage_rank_slice* slices, int64_t row_pad,
+                                int32_t n_slabs) {
+  RankLayout o;
+  if (!dims || !slices || !rank_lay_out(n_layers, dims, slices, row_pad, n_slabs, o)) return CSL_E_INVALID;
+  return o.total;
+}
+
+int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_rank_slice* sl,
+                              const float* const* weights, const float* const* biases, const float* feat, int64_t ldf,
+                              const int32_t* feat_rows, const int32_t* seed_ids, const int32_t* label_rows,
+                              const int64_t* labels, float scale, int64_t row_pad, int32_t n_slabs,
+                              csl_exchange_fn exchange, void* user, float* grads, float* loss, float* workspace,
+                              int64_t workspace_floats, void* stream) {
+  int k = -1;
+  s_err[0] = 0;
+  RankLayout o;
+  if (!dims || !sl || !weights || !biases || !grads || !loss || !exchange ||
+      !rank_lay_out(n_layers, dims, sl, row_pad, n_slabs, o)) {
+    snprintf(s_err, sizeof(s_err), "bad argument or unsupported model (widths multiples of 4, <= 256 classes, 1..%d layers, "
+             "n_in of a layer = n_owned of the layer below)", CSL_MAX_LAYERS);
+    return CSL_E_INVALID;
+  }
+  if (o.total > workspace_floats || (o.total > 0 && (!workspace || ((uintptr_t)workspace & 15)))) {
+    snprintf(s_err, sizeof(s_err), "workspace: %lld floats needed, %lld given", (long long)o.total, (long long)workspace_floats);
+    return CSL_E_INVALID;
+  }
+  const int L = n_layers;
+  float* ws = workspace;
+  float *gW[CSL_MAX_LAYERS], *gb[CSL_MAX_LAYERS];
+  {
+    int64_t at = 0;
+    for (int j = 0; j < L; j++) {
+      gW[j] = grads + at, at += (int64_t)dims[j + 1] * 2 * dims[j];
+      gb[j] = grads + at, at += dims[j + 1];
+    }
+  }
+#define XCHG(layer, backward, src, dst, width)                                                     \
+  do {                                                                                             \
+    const int rc_ = exchange(user, (layer), (backward), (src), (dst), (width), stream);            \
+    if (rc_ < 0) {                                                                                 \
+      snprintf(s_err, sizeof(s_err), "the exchange callback failed (%d), layer %d, %s", rc_, (layer), \
+               (backward) ? "backward" : "forward");                                               \
+      return rc_;                                                                                  \
+    }                                                                                              \
+  } while (0)
+  // ---- forward
+  k = 0;
+  STEP(csl_gather_rows_f32(feat, ldf, feat_rows, sl[0].n_in, ws + o.x0, dims[0], dims[0], stream));
+  for (k = 0; k < L; k++) {
+    const int32_t in = dims[k], out = dims[k + 1];
+    const csl_sage_rank_slice& s = sl[k];
+    const float* x = k == 0 ? ws + o.x0 : ws + o.y[k - 1];
+    // partial sums of the rows peers own, straight into the send buffer; then the rows this part owns
+    STEP(csl_spmm_sum_compact_f32(s.indptr, s.indices, s.from_all, s.n_from, x, in, ws + o.send[k], in, in, stream));
+    XCHG(k, 0, ws + o.send[k], ws + o.recv[k], in);
+    STEP(csl_spmm_sum_f32(s.indptr, s.indices, s.owned_out_nodes, s.n_owned, x, in, ws + o.agg[k], in, in, stream));
+    STEP(csl_scatter_add_rows_atomic_f32(ws + o.agg[k], in, s.to_all, s.n_to, ws + o.recv[k], in, in, stream));
+    STEP(csl_sage_cat_f32(nullptr, nullptr, s.self_ids_in, s.owned_out_nodes, s.owned_degree, nullptr, x, in, ws + o.agg[k],
+                          in, s.n_owned, o.mp[k], ws + o.cat[k], 2 * (int64_t)in, in, 0, stream));
+    STEP(csl_gemm_f32(0, 1, o.mp[k], out, 2 * (int64_t)in, ws + o.cat[k], 2 * (int64_t)in, 0, weights[k], 2 * (int64_t)in, 0,
+                      ws + o.y[k], out, 0, 1, biases[k], k + 1 < L ? 1 : 0, stream));
+  }
+  const float* r_src[12];
+  float* r_dst[12];
+  int64_t r_nblk[12];
+  int32_t r_h[12];
+  int nr = 0;
+  auto defer = [&](const float* src, int64_t nblk, int32_t h, float* dst) {
+    r_src[nr] = src, r_nblk[nr] = nblk, r_h[nr] = h, r_dst[nr] = dst;
+    nr++;
+  };
+  // ---- loss over the seeds this part owns (the caller's `scale` = 1 / seeds of the WHOLE minibatch)
+  k = L - 1;
+  {
+    const int32_t C = dims[L];
+    STEP(csl_softmax_ce_partial_f32(ws + o.y[k], C, sl[k].n_owned, o.mp[k], C, seed_ids, label_rows, labels, scale,
+                                    ws + o.gy[k], C, ws + o.lpart, ws + o.bpart[k], stream));
+    defer(ws + o.bpart[k], o.bblocks[k], C, gb[k]);
+    defer(ws + o.lpart, o.lblocks, 1, loss);
+  }
+  // ---- backward
+  for (k = L - 1; k >= 0; k--) {
+    const int32_t in = dims[k], out = dims[k + 1];
+    const csl_sage_rank_slice& s = sl[k];
+    const int64_t mp = o.mp[k], wn = (int64_t)out * 2 * in;
+    if (mp == 0) {
+      if (hipMemsetAsync(gW[k], 0, sizeof(float) * wn, (hipStream_t)stream) != hipSuccess) return CSL_E_HIP;
+    } else if (o.slabbed[k]) {
+      const int64_t rs = mp / n_slabs;
+      STEP(csl_gemm_f32(1, 0, out, 2 * (int64_t)in, rs, ws + o.gy[k], out, rs * out, ws + o.cat[k], 2 * (int64_t)in,
+                        rs * 2 * in, ws + o.slabs[k], 2 * (int64_t)in, wn, n_slabs, nullptr, 0, stream));
+      defer(ws + o.slabs[k], n_slabs, (int32_t)wn, gW[k]);
+    } else {
+      STEP(csl_gemm_f32(1, 0, out, 2 * (int64_t)in, mp, ws + o.gy[k], out, 0, ws + o.cat[k], 2 * (int64_t)in, 0, gW[k],
+                        2 * (int64_t)in, 0, 1, nullptr, 0, stream));
+    }
+    if (k == 0) break;   // (no gradient flows into the input features; the deepest layer's exchange has no backward)
+    STEP(csl_gemm_f32(0, 0, mp, 2 * (int64_t)in, out, ws + o.gy[k], out, 0, weights[k], 2 * (int64_t)in, 0, ws + o.gcat[k],
+                      2 * (int64_t)in, 0, 1, nullptr, 0, stream));
+    // operand gradient -> self rows of gx and owned rows of the merged sums' gradient (both zeroed inside)
+    STEP(csl_sage_cat_rows_bwd_f32(s.self_ids_in, s.owned_out_nodes, s.owned_degree, s.n_owned, ws + o.gcat[k],
+                                   2 * (int64_t)in, ws + o.gx[k], s.n_in, ws + o.agg[k], s.n_out, in, stream));
+    // what this part received forward gets its gradient back; the reverse exchange returns the gradients of the
+    // partial sums this part sent
+    STEP(csl_gather_rows_f32(ws + o.agg[k], in, s.to_all, s.n_to, ws + o.recv[k], in, in, stream));
+    XCHG(k, 1, ws + o.recv[k], ws + o.send[k], in);
+    STEP(csl_spmm_sum_bwd_f32(s.indptr, s.indices, s.owned_out_nodes, s.n_owned, ws + o.agg[k], in, 0, ws + o.gx[k], in, in,
+                              stream));
+    STEP(csl_spmm_sum_bwd_f32(s.indptr, s.indices, s.from_all, s.n_from, ws + o.send[k], in, 1, ws + o.gx[k], in, in,
+                              stream));
+    // ReLU mask of the layer below, padding of its GEMM operand, its bias column sums (first stage)
+    if (o.mp[k - 1] > 0)
+      STEP(csl_relu_bwd_colsum_f32(ws + o.gx[k], in, ws + o.y[k - 1], in, s.n_in, o.mp[k - 1], ws + o.gy[k - 1], in,
+                                   nullptr, ws + o.bpart[k - 1], in, stream));
+    defer(ws + o.bpart[k - 1], o.mp[k - 1] > 0 ? o.bblocks[k - 1] : 0, in, gb[k - 1]);
+  }
+  k = -1;
+  STEP(csl_reduce_multi_f32(nr, r_src, r_nblk, r_h, r_dst, stream));
+#undef XCHG
+  return CSL_OK;
+}
+
+}  // extern "C"
