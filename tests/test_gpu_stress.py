@@ -140,7 +140,8 @@ def test_empty_round_and_empty_streams(abi):
 # CSLICER_FUZZ_SEEDS=N / CSLICER_FUZZ_SCALE=K widen the campaign (one-off runs after the kernel rewrites of
 # round 1: 400 seeds at scale 1 and 60 seeds at scale 25 (graphs up to 150 k nodes, batches up to 7500), all clean;
 # after round 2's -- last-block scans, pre-written flags, repeated seed ids, edge stream compared too -- 300 seeds at
-# scale 1 and 50 at scale 25, all clean)
+# scale 1 and 50 at scale 25, all clean; with the slices by source and part masks in graph mode, the multi-pass bucket
+# path and the new generator: 250 seeds at scale 1 and 40 at scale 20, all clean)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CSLICER_FUZZ_SEEDS", "12"))))
 def test_randomised_configurations(abi, orc, seed):
     """Random graph shape, fanouts (incl. 1 and > 16), parts, batch, streams, workload table."""
@@ -161,8 +162,11 @@ def test_randomised_configurations(abi, orc, seed):
     if not mode_graph and rng.random() < 0.35:
         # strict mode takes minibatches with repeated seed ids (bipartite.cpp:3-17): the node order itself repeats
         perm = rng.integers(0, n, size=n)
+    transposed = mode_graph and bool(rng.random() < 0.6)     # graph mode: also the slices by source
+    pmask = int(rng.integers(1, 1 << P)) if mode_graph and rng.random() < 0.3 else 0   # ... of some parts only
     e = abi.Engine(indptr, indices, n_parts=P, fanouts=fan, max_batch=B, n_streams=S, n_slots=2, workload=wl,
-                   mode=abi.MODE_GRAPH if mode_graph else abi.MODE_STRICT, flags=abi.FLAG_KEEP_CANDIDATES)
+                   mode=abi.MODE_GRAPH if mode_graph else abi.MODE_STRICT, part_mask=pmask,
+                   flags=abi.FLAG_KEEP_CANDIDATES | (abi.FLAG_TRANSPOSE if transposed else 0))
     e.set_nodes(perm)
     oracles = [orc.Oracle(indptr, indices, n_parts=P, fanouts=fan, workload=wl) for _ in range(S)]
     nb = (n + B - 1) // B
@@ -176,6 +180,10 @@ def test_randomised_configurations(abi, orc, seed):
                 got, want = e.graph_dict(s, slot=r & 1), oracles[s].sample_graph(seeds)
                 for l in range(L):
                     for g in range(P):
+                        if pmask and not (pmask >> g) & 1:
+                            continue          # (a masked-out part's lists are not written; its sizes still are)
+                        if transposed:
+                            _check_by_source(got["layers"][l][g], l == L - 1, tag)
                         for key in ("in_nodes", "out_nodes", "indptr", "indices", "owned_out_nodes", "self_ids_in",
                                     "self_ids_out", "owned_degree"):
                             np.testing.assert_array_equal(got["layers"][l][g][key], want["layers"][l][g][key],
@@ -188,6 +196,23 @@ def test_randomised_configurations(abi, orc, seed):
             else:
                 assert_same_sample(e.sample_dict(s, slot=r & 1), oracles[s].sample(seeds), what=tag)
     e.close()
+
+
+def _check_by_source(bp, deepest, tag):
+    """t_indptr / t_indices (FLAG_TRANSPOSE) against a numpy transposition of the slice's own CSR + self lists"""
+    if deepest:
+        assert len(bp["t_indptr"]) == 0 and len(bp["t_indices"]) == 0, tag
+        return
+    n_in = len(bp["in_nodes"])
+    if n_in == 0 and len(bp["t_indptr"]) == 0:
+        return
+    rows = np.repeat(np.arange(len(bp["out_nodes"]), dtype=np.int64), np.diff(bp["indptr"]))
+    u = np.concatenate([bp["indices"].astype(np.int64), bp["self_ids_in"].astype(np.int64)])
+    val = np.concatenate([rows, ~bp["self_ids_out"].astype(np.int64)])
+    order = np.lexsort((val, u))
+    np.testing.assert_array_equal(bp["t_indptr"], np.concatenate([[0], np.cumsum(np.bincount(u, minlength=n_in))]),
+                                  err_msg=tag + " t_indptr")
+    np.testing.assert_array_equal(bp["t_indices"], val[order], err_msg=tag + " t_indices")
 
 
 def test_running_totals_are_exact(abi, orc):
