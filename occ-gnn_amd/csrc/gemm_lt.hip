@@ -161,7 +161,10 @@ int run(const Plan& p, const float* A, const float* B, float* C, const float* bi
   return 0;
 }
 
-int make_plan(const Key& key, Plan& p, const float* A, const float* B, float* C, const float* bias, hipStream_t st) {
+// *ran: the GEMM itself has been issued (with the algorithm the plan keeps) as part of making the plan
+int make_plan(const Key& key, Plan& p, const float* A, const float* B, float* C, const float* bias, hipStream_t st,
+              bool* ran) {
+  *ran = false;
   int transa, transb, batch, epi;
   long long m, n, k, lda, ldb, ldc, sa, sb, sc;
   std::tie(transa, transb, m, n, k, lda, ldb, ldc, batch, sa, sb, sc, epi) = key;
@@ -194,7 +197,10 @@ int make_plan(const Key& key, Plan& p, const float* A, const float* B, float* C,
     if (ci != g.classes.end()) {
       p.algo = ci->second.first;
       p.ws = ci->second.second;
-      if (run(p, A, B, C, bias, st) == 0) return 0;  // (else: the library refuses it for this size -- time afresh)
+      if (run(p, A, B, C, bias, st) == 0) {  // (else: the library refuses it for this size -- time afresh)
+        *ran = true;
+        return 0;
+      }
     }
   }
   const float one = 1.f, zero = 0.f;
@@ -211,6 +217,7 @@ int make_plan(const Key& key, Plan& p, const float* A, const float* B, float* C,
         p.ws = wsz;
         if (run(p, A, B, C, bias, st) == 0) {
           g.classes[cls] = std::make_pair(p.algo, p.ws);
+          *ran = true;
           return 0;
         }
       }
@@ -360,9 +367,11 @@ int csl_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k
   auto it = g.plans.find(key);
   if (it == g.plans.end()) {
     Plan p;
-    const int r = make_plan(key, p, A, B, C, bias, (hipStream_t)stream);
+    bool ran = false;
+    const int r = make_plan(key, p, A, B, C, bias, (hipStream_t)stream, &ran);
     if (r) return r;
     it = g.plans.emplace(key, p).first;
+    if (ran) return 0;
   }
   return run(it->second, A, B, C, bias, (hipStream_t)stream);
 }

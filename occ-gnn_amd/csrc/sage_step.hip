@@ -29,8 +29,12 @@ namespace {
 
 thread_local char s_err[200];
 
+// GEMM row counts repeat from minibatch to minibatch (a plan per shape: gemm_lt.hip): multiples of row_pad for tall
+// operands, of 256 below that (a rank of an N-GPU job sees a few hundred to a few thousand rows per layer)
 inline int64_t pad_rows(int64_t m, int64_t row_pad) {
-  return (row_pad > 0 && m >= row_pad) ? (m + row_pad - 1) / row_pad * row_pad : m;
+  if (row_pad <= 0) return m;
+  const int64_t q = m >= row_pad ? row_pad : (row_pad < 256 ? row_pad : 256);
+  return (m + q - 1) / q * q;
 }
 inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }  // every buffer starts 16-byte aligned
 
