@@ -325,6 +325,17 @@ def _nccl_runs(Trainer, dist, indptr, indices, feats, labels, perm, kind, out):
         t.set_nodes(perm)
         out.append(t.run(4))
         t.close()
+    if kind == "sage":
+        # the data-parallel trainer's one collective -- the all-reduce of the flat gradient buffer -- over RCCL too
+        # (with a world of one it is skipped by default: forced here); same numbers as the plain single-GPU run
+        from cslicer.train import DataParallelTrainer
+        t = DataParallelTrainer(indptr, indices, feats, labels, 5, 0, 1, dist, batch=128, fanouts=(10, 5), streams=2,
+                                hidden=16, lr=1e-2)
+        t.grad_sync = lambda flat: dist.all_reduce(flat)
+        t.set_nodes(perm)
+        dp = t.run(4)
+        t.close()
+        np.testing.assert_allclose(dp, out[0], rtol=1e-6)
 
 
 @pytest.mark.parametrize("kind", ["sage", "gat"])
