@@ -459,7 +459,11 @@ class CSlicer {
   // helpers of the converter thread (int32 -> long widening of a sample's 12 BiPartites); CSLICER_CONVERT_THREADS
   static int convert_helpers() {
     const char* e = getenv("CSLICER_CONVERT_THREADS");
-    const int n = e ? atoi(e) : 3;
+    // default: half the CPUs, 3..8 (16 CPUs: 5.5 k samples/s with 3 helpers, 7.1-7.4 k with 8; beyond that the consumer's
+    // own deletes of the previous sample set the pace)
+    int def = (int)std::thread::hardware_concurrency() / 2;
+    def = def < 3 ? 3 : (def > 8 ? 8 : def);
+    const int n = e ? atoi(e) : def;
     return n < 0 ? 0 : (n > 15 ? 15 : n);
   }
   MiniPool pool_{convert_helpers()};
