@@ -271,14 +271,18 @@ typedef struct {
 } csl_sage_rank_slice;
 typedef int (*csl_exchange_fn)(void* user, int32_t layer, int32_t backward, const float* src, float* dst, int32_t width,
                                void* stream);
+/* optional second callback: with it, `exchange` may merely START the exchange on a stream of the caller's (after making
+ * that stream wait for what `stream` holds so far) and `wait` makes `stream` wait for its end; the step calls it right
+ * before the received rows are first used, so the rows that stay on the GPU are aggregated while the others travel */
+typedef int (*csl_exchange_wait_fn)(void* user, int32_t layer, int32_t backward, void* stream);
 int64_t csl_sage_rank_workspace(int32_t n_layers, const int32_t* dims, const csl_sage_rank_slice* slices, int64_t row_pad,
                                 int32_t n_slabs);
 int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_rank_slice* slices,
                               const float* const* weights, const float* const* biases, const float* feat, int64_t ldf,
                               const int32_t* feat_rows, const int32_t* seed_ids, const int32_t* label_rows,
                               const int64_t* labels, float scale, int64_t row_pad, int32_t n_slabs,
-                              csl_exchange_fn exchange, void* user, float* grads, float* loss, float* workspace,
-                              int64_t workspace_floats, void* stream);
+                              csl_exchange_fn exchange, csl_exchange_wait_fn wait, void* user, float* grads, float* loss,
+                              float* workspace, int64_t workspace_floats, void* stream);
 
 #ifdef __cplusplus
 }

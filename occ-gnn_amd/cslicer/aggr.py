@@ -67,8 +67,8 @@ def _lib():
         L.csl_gemm_save_plans.argtypes = [C.c_char_p]
         L.csl_sage_rank_workspace.argtypes = [i32, vp, vp, i64, i32]
         L.csl_sage_rank_workspace.restype = i64
-        L.csl_sage_rank_fwd_bwd_f32.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, f32, i64, i32, EXCHANGE_FN, vp,
-                                                vp, vp, vp, i64, vp]
+        L.csl_sage_rank_fwd_bwd_f32.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, f32, i64, i32, EXCHANGE_FN,
+                                                EXCHANGE_WAIT_FN, vp, vp, vp, vp, i64, vp]
         L.csl_gat_logits_bwd_acc_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp]
         L.csl_gat_finish_fwd_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
         L.csl_gat_finish_bwd_f32.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]
@@ -388,6 +388,7 @@ class SageRankSlice(C.Structure):
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)
 
 
 class SageRankStep(object):
@@ -396,11 +397,16 @@ class SageRankStep(object):
     (splitgnn.DistComm: all_to_all_single over RCCL, gloo in the tests).  Gradients of this rank's share land in
     `self.grads` (W_0, b_0, ...) for the caller's all-reduce and aggr.Adam.step(flat_grads=...)."""
 
-    def __init__(self, model, row_pad, n_slabs, comm):
+    def __init__(self, model, row_pad, n_slabs, comm, overlap=False):
         ws, bs = [c.fc.weight for c in model.convs], [c.fc.bias for c in model.convs]
         self.L = len(ws)
         self.dims = [ws[0].shape[1] // 2] + [w.shape[0] for w in ws]
         self._params = ws + bs
+        # overlap: every exchange runs on the communicator's side stream while the rows that stay on this GPU are
+        # aggregated (dist_sageconv.py:57-64); same numbers, different schedule
+        self.overlap = bool(overlap)
+        self._done = {}
+        self._cb_wait = EXCHANGE_WAIT_FN(self._wait)
         self._dims = (C.c_int32 * (self.L + 1))(*self.dims)
         self._w = (C.c_void_p * self.L)(*[w.data_ptr() for w in ws])
         self._b = (C.c_void_p * self.L)(*[b.data_ptr() for b in bs])
@@ -422,9 +428,29 @@ class SageRankStep(object):
         try:
             s = self._cur[layer]
             send, recv = (s.to_counts, s.from_counts) if backward else (s.from_counts, s.to_counts)
-            self.comm.exchange_into(self._view(dst, sum(recv), width), self._view(src, sum(send), width), send, recv)
+            out, inp = self._view(dst, sum(recv), width), self._view(src, sum(send), width)
+            if not self.overlap:
+                self.comm.exchange_into(out, inp, send, recv)
+                return 0
+            main, side = torch.cuda.current_stream(), self.comm.side_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                self.comm.exchange_into(out, inp, send, recv)
+                done = torch.cuda.Event()
+                done.record(side)
+            self._done[(layer, backward)] = done
             return 0
         except Exception as ex:      # an exception cannot cross the C frame: reported after the native call returns
+            self._exc = ex
+            return -1
+
+    def _wait(self, user, layer, backward, stream):
+        try:
+            torch.cuda.current_stream().wait_event(self._done.pop((layer, backward)))
+            return 0
+        except Exception as ex:
             self._exc = ex
             return -1
 
@@ -448,7 +474,8 @@ class SageRankStep(object):
         self._cur, self._exc = slices, None
         rc = L.csl_sage_rank_fwd_bwd_f32(self.L, self._dims, self._sl, self._w, self._b, feat.data_ptr(), feat.stride(0),
                                          _p(feat_rows), _p(seed_ids), _p(label_rows) if label_rows is not None else None,
-                                         labels.data_ptr(), float(scale), self.row_pad, self.n_slabs, self._cb, None,
+                                         labels.data_ptr(), float(scale), self.row_pad, self.n_slabs, self._cb,
+                                         self._cb_wait if self.overlap else EXCHANGE_WAIT_FN(0), None,
                                          self.grads.data_ptr(), loss_out.data_ptr(), self._ws.data_ptr(),
                                          self._ws.numel(), _stream())
         self._cur = None

@@ -103,11 +103,13 @@ class Trainer(object):
         self.comm = splitgnn.DistComm(device=self.dev) if self.rank_path else None
         self.overlap = overlap
         # one process per part: the same idea -- everything between two boundary exchanges is issued by one native call,
-        # the exchanges come back as callbacks into self.comm (CSLICER_PY_STEP=1 / overlap=True: the autograd path)
+        # the exchanges come back as callbacks into self.comm, on its side stream with overlap=True (CSLICER_PY_STEP=1: the
+        # autograd path)
         self.native_rank = None
-        if (self.rank_path and model == "sage" and F % 4 == 0 and hidden % 4 == 0 and n_classes <= 256 and not overlap
+        if (self.rank_path and model == "sage" and F % 4 == 0 and hidden % 4 == 0 and n_classes <= 256
                 and not os.environ.get("CSLICER_PY_STEP")):
-            self.native_rank = aggr.SageRankStep(self.model, splitgnn.ROW_PAD, splitgnn.SPLIT_K, self.comm)
+            self.native_rank = aggr.SageRankStep(self.model, splitgnn.ROW_PAD, splitgnn.SPLIT_K, self.comm,
+                                                 overlap=overlap)
             self._loss_ring, self._ring_at = torch.zeros((4096,), dtype=torch.float32, device=self.dev), 0
         self.t_forward = self.t_slice = 0.0
         self.steps_done = 0

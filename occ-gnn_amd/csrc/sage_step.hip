@@ -286,8 +286,8 @@ int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_s
                               const float* const* weights, const float* const* biases, const float* feat, int64_t ldf,
                               const int32_t* feat_rows, const int32_t* seed_ids, const int32_t* label_rows,
                               const int64_t* labels, float scale, int64_t row_pad, int32_t n_slabs,
-                              csl_exchange_fn exchange, void* user, float* grads, float* loss, float* workspace,
-                              int64_t workspace_floats, void* stream) {
+                              csl_exchange_fn exchange, csl_exchange_wait_fn wait, void* user, float* grads, float* loss,
+                              float* workspace, int64_t workspace_floats, void* stream) {
   int k = -1;
   s_err[0] = 0;
   RankLayout o;
@@ -320,6 +320,19 @@ int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_s
       return rc_;                                                                                  \
     }                                                                                              \
   } while (0)
+  // `wait` given: `exchange` only STARTS the exchange (on a stream of the caller's) and `wait` makes `stream` wait for
+  // it -- called right before the received rows are first used, so the rows that never leave the GPU are aggregated
+  // while the boundary rows travel (dist_sageconv.py:57-64 on a side stream)
+#define XWAIT(layer, backward)                                                                     \
+  do {                                                                                             \
+    if (wait) {                                                                                    \
+      const int rc_ = wait(user, (layer), (backward), stream);                                     \
+      if (rc_ < 0) {                                                                               \
+        snprintf(s_err, sizeof(s_err), "the exchange-wait callback failed (%d), layer %d", rc_, (layer)); \
+        return rc_;                                                                                \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
   // ---- forward
   k = 0;
   STEP(csl_gather_rows_f32(feat, ldf, feat_rows, sl[0].n_in, ws + o.x0, dims[0], dims[0], stream));
@@ -331,6 +344,7 @@ int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_s
     STEP(csl_spmm_sum_compact_f32(s.indptr, s.indices, s.from_all, s.n_from, x, in, ws + o.send[k], in, in, stream));
     XCHG(k, 0, ws + o.send[k], ws + o.recv[k], in);
     STEP(csl_spmm_sum_f32(s.indptr, s.indices, s.owned_out_nodes, s.n_owned, x, in, ws + o.agg[k], in, in, stream));
+    XWAIT(k, 0);
     STEP(csl_scatter_add_rows_atomic_f32(ws + o.agg[k], in, s.to_all, s.n_to, ws + o.recv[k], in, in, stream));
     STEP(csl_sage_cat_f32(nullptr, nullptr, s.self_ids_in, s.owned_out_nodes, s.owned_degree, nullptr, x, in, ws + o.agg[k],
                           in, s.n_owned, o.mp[k], ws + o.cat[k], 2 * (int64_t)in, in, 0, stream));
@@ -383,6 +397,7 @@ int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_s
     XCHG(k, 1, ws + o.recv[k], ws + o.send[k], in);
     STEP(csl_spmm_sum_bwd_f32(s.indptr, s.indices, s.owned_out_nodes, s.n_owned, ws + o.agg[k], in, 0, ws + o.gx[k], in, in,
                               stream));
+    XWAIT(k, 1);
     STEP(csl_spmm_sum_bwd_f32(s.indptr, s.indices, s.from_all, s.n_from, ws + o.send[k], in, 1, ws + o.gx[k], in, in,
                               stream));
     // ReLU mask of the layer below, padding of its GEMM operand, its bias column sums (first stage)
@@ -394,6 +409,7 @@ int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_s
   k = -1;
   STEP(csl_reduce_multi_f32(nr, r_src, r_nblk, r_h, r_dst, stream));
 #undef XCHG
+#undef XWAIT
   return CSL_OK;
 }
 
