@@ -521,7 +521,7 @@ def main():
         barrier()
         t_e2e = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)
         work = tr.step_work(args.e2e_steps) if args.e2e_model == "sage" else None
-        tr_native = getattr(tr, "native", None) is not None
+        tr_native = getattr(tr, "native", None) is not None or getattr(tr, "native_rank", None) is not None
         tr.close()
         roof = None
         if work is not None:
