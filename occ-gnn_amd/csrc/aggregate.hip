@@ -666,32 +666,46 @@ struct ReduceJobs {
   long long nblk[RM_MAX];
   int H[RM_MAX];
   int first_block[RM_MAX + 1];
+  int vec[RM_MAX];  // H % 4 == 0 and 16-byte aligned operands: float4 columns
   int count;
 };
-__global__ __launch_bounds__(BLK) void k_reduce_multi(ReduceJobs jb) {
-  int j = 0;
-  while (j + 1 < jb.count && (int)blockIdx.x >= jb.first_block[j + 1]) j++;
-  const int H = jb.H[j];
-  const long long nblk = jb.nblk[j];
-  const float* __restrict__ partial = jb.src[j];
-  const int c = ((int)blockIdx.x - jb.first_block[j]) * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  __shared__ float s_q[BLK];
-  float acc = 0.f;
+// A block is RM_L lanes along the columns x RM_G groups along the partial rows: a bias job has ~10^3 partial rows and only
+// a few hundred columns, so the rows must be split finely (with 64 lanes x 4 groups its 320-long serial sums were 25 us of
+// a 29 us launch); a slab job has 32 rows and 10^5 columns and is happy either way.
+constexpr int RM_L = 16, RM_G = BLK / RM_L;
+template <typename V>
+__device__ __forceinline__ void reduce_job(const float* __restrict__ partial, float* __restrict__ dst, long long nblk,
+                                           int H, int block_in_job) {
+  constexpr int W = sizeof(V) / 4, U = 4;
+  const int lane = threadIdx.x % RM_L, q = threadIdx.x / RM_L;
+  const int c = (block_in_job * RM_L + lane) * W;
+  __shared__ V s_q[BLK];
+  V acc = {};
   if (c < H) {
-    constexpr int Q = BLK / 64, U = 8;
     long long b = q;
-    for (; b + (U - 1) * Q < nblk; b += U * Q) {
-      float v[U];
+    for (; b + (U - 1) * RM_G < nblk; b += U * RM_G) {
+      V v[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) v[u] = partial[(b + u * Q) * H + c];
+      for (int u = 0; u < U; u++) v[u] = *reinterpret_cast<const V*>(partial + (b + u * RM_G) * H + c);
 #pragma unroll
-      for (int u = 0; u < U; u++) acc += v[u];
+      for (int u = 0; u < U; u++) acc = acc + v[u];
     }
-    for (; b < nblk; b += Q) acc += partial[b * H + c];
+    for (; b < nblk; b += RM_G) acc = acc + *reinterpret_cast<const V*>(partial + b * H + c);
   }
   s_q[threadIdx.x] = acc;
   __syncthreads();
-  if (q == 0 && c < H) jb.dst[j][c] = s_q[threadIdx.x] + s_q[threadIdx.x + 64] + s_q[threadIdx.x + 128] + s_q[threadIdx.x + 192];
+  for (int o = RM_G / 2; o > 0; o >>= 1) {  // tree over the groups
+    if (q < o) s_q[threadIdx.x] = s_q[threadIdx.x] + s_q[threadIdx.x + o * RM_L];
+    __syncthreads();
+  }
+  if (q == 0 && c < H) *reinterpret_cast<V*>(dst + c) = s_q[threadIdx.x];
+}
+__global__ __launch_bounds__(BLK) void k_reduce_multi(ReduceJobs jb) {
+  int j = 0;
+  while (j + 1 < jb.count && (int)blockIdx.x >= jb.first_block[j + 1]) j++;
+  const int bj = (int)blockIdx.x - jb.first_block[j];
+  if (jb.vec[j]) reduce_job<float4>(jb.src[j], jb.dst[j], jb.nblk[j], jb.H[j], bj);
+  else reduce_job<float>(jb.src[j], jb.dst[j], jb.nblk[j], jb.H[j], bj);
 }
 
 // ---- Adam (python/train.py:83 torch.optim.Adam, no weight decay, no amsgrad) over every parameter tensor of the
@@ -1187,8 +1201,9 @@ int csl_reduce_multi_f32(int32_t count, const float* const* src, const int64_t* 
     if (!dst[j] || (nblk[j] > 0 && !src[j])) return CSL_E_INVALID;
     const int k = jb.count++;
     jb.src[k] = src[j], jb.dst[k] = dst[j], jb.nblk[k] = nblk[j], jb.H[k] = H[j];
+    jb.vec[k] = H[j] % 4 == 0 && aligned16(dst[j]) && (nblk[j] == 0 || aligned16(src[j]));
     jb.first_block[k] = at;
-    at += (H[j] + 63) / 64;
+    at += jb.vec[k] ? (H[j] + 4 * RM_L - 1) / (4 * RM_L) : (H[j] + RM_L - 1) / RM_L;
   }
   jb.first_block[jb.count] = at;
   if (at > 0) hipLaunchKernelGGL(k_reduce_multi, dim3((unsigned)at), dim3(BLK), 0, (hipStream_t)stream, jb);
