@@ -193,9 +193,11 @@ def _rank_body(rank, world, q, overlap, kind, dist, table=False):
 @pytest.mark.parametrize("overlap,kind,table,world", [(False, "sage", False, 2), (True, "sage", False, 2),
                                                       (False, "gat", False, 2), (False, "sage", True, 2),
                                                       (True, "sage", True, 2), (False, "sage", True, 3),
-                                                      (False, "gat", True, 3)],
+                                                      (False, "gat", True, 3), (False, "sage", False, 4),
+                                                      (True, "sage", True, 4)],
                          ids=["sequential", "side-stream-overlap", "gat", "partition-table", "partition-table-overlap",
-                              "three-ranks-one-nearly-empty", "three-ranks-one-nearly-empty-gat"])
+                              "three-ranks-one-nearly-empty", "three-ranks-one-nearly-empty-gat", "four-ranks",
+                              "four-ranks-table-overlap"])
 def test_two_ranks_match_single_process_two_parts(overlap, kind, table, world):
     import torch.multiprocessing as mp
     from cslicer import _abi, splitgnn
