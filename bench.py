@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--e2e-steps", type=int, default=128,
                     help="end-to-end training minibatches for the secondary iters/s figure (0 = skip)")
     ap.add_argument("--no-e2e-multi", action="store_true", help="several GPUs: skip the split-parallel training leg")
+    ap.add_argument("--e2e-overlap", action="store_true",
+                    help="several GPUs: run every boundary exchange of the split-parallel step on a side HIP stream while the "
+                         "rows that stay on the GPU are aggregated (same numbers; off by default until it can be measured on "
+                         "a multi-GPU node)")
     ap.add_argument("--no-e2e-dp", action="store_true",
                     help="several GPUs: skip the data-parallel training leg (e2e.data_parallel)")
     ap.add_argument("--e2e-timeout", type=float, default=180.0, help="several GPUs: watchdog of the e2e leg, seconds")
@@ -509,7 +513,8 @@ def main():
         labels = lambda own: synthetic_node_data(N, 1, args.e2e_classes, seed=0, rows=own)[1]            # noqa: E731
         tr = Trainer(indptr, indices, feats, labels, args.e2e_classes, rank=rank, world=world, fanouts=fan,
                      batch=B, streams=args.e2e_streams, hidden=args.e2e_hidden, device=device, dist=dist,
-                     model=args.e2e_model, heads=args.e2e_heads, feat_dim=args.e2e_feat)
+                     model=args.e2e_model, heads=args.e2e_heads, feat_dim=args.e2e_feat,
+                     overlap=bool(args.e2e_overlap and world > 1 and args.e2e_model == "sage"))
         tr.set_nodes(perm)
         tr.run(48)                       # warm-up: more than one engine round (allocator, rng window, GEMM plans)
         barrier()
@@ -543,6 +548,7 @@ def main():
             # one native call per minibatch (csl_sage_fwd_bwd_f32, direct hipBLASLt GEMMs timed per shape) or the
             # kernels issued from Python through torch autograd (then with torch's GEMMs and these selections)
             "native_step": tr_native,
+            "exchange_overlap": bool(args.e2e_overlap and world > 1 and args.e2e_model == "sage"),
             "tuned_gemm_selections": bool(tuned) and not tr_native,
             "iters_per_sec": args.e2e_steps / t_e2e, "ms_per_iter": 1e3 * t_e2e / args.e2e_steps,
             "steps": args.e2e_steps,
