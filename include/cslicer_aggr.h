@@ -75,6 +75,14 @@ int csl_gat_bwd_f32(const int32_t* indptr, const int32_t* indices, int64_t n_row
                     const float* g_n, float* g_el, float* g_er, float* g_z, void* stream);
 
 
+/* The same gradients BY SOURCE, over the slicer's slice by source (cslicer_hip.h CSL_T_INDPTR / CSL_T_INDICES with
+ * CSL_FLAG_TRANSPOSE_ALL; self entries, negative, are skipped): g_z [n_pad, H*D] and g_el [n_src, H] are WRITTEN (each
+ * row once: nothing to pre-zero, no atomics on them; rows [n_src, n_pad) of g_z are zeroed), g_er [n_rows, H] is
+ * ACCUMULATED with fp32 atomics (zero it first: H floats per edge instead of H*D). */
+int csl_gat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, int64_t n_src, int64_t n_pad, const float* el,
+                      const float* er, const float* z, int32_t H, int32_t D, float slope, const float* m_in,
+                      const float* g_s, const float* g_n, float* g_el, float* g_er, float* g_z, void* stream);
+
 /* GAT attention logits (DistGATConv.project): el[r, h] = <z[r, h, :], attn_l[h, :]>, er likewise; z [n, H*D],
  * attn_* [H, D], el/er [n, H]; D % 4 == 0, D <= 256, 16-byte aligned.  Backward: g_z [n, H*D] is WRITTEN
  * (g_el a_l + g_er a_r), g_attn_l / g_attn_r [H, D] are the sums over the rows (two-stage, no atomics);

@@ -23,6 +23,7 @@ MODE_STRICT, MODE_GRAPH = 0, 1
 FLAG_SERIAL_ROUNDS = 1
 FLAG_KEEP_CANDIDATES = 2
 FLAG_TRANSPOSE = 4   # graph mode: also the slices by source (T_INDPTR / T_INDICES), every layer but the deepest
+FLAG_TRANSPOSE_ALL = 8   # ... the deepest too (with FLAG_TRANSPOSE)
 LIST_KINDS = {
     "in_nodes": IN_NODES, "out_nodes": OUT_NODES, "owned_out_nodes": OWNED_OUT_NODES,
     "self_ids_in": SELF_IDS_IN, "self_ids_out": SELF_IDS_OUT, "to_ids": TO_IDS, "from_ids": FROM_IDS,

@@ -21,7 +21,8 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_sage_cat_bwd_t_f32", "csl_sage_cat_bwd_t_scratch", "csl_gemm_f32", "csl_gemm_last_error",
            "csl_sum_slabs_f32", "csl_sage_fwd_bwd_f32", "csl_sage_fwd_bwd_workspace", "csl_sage_last_error",
            "csl_gemm_save_plans", "csl_gemm_load_plans", "csl_softmax_ce_partial_f32", "csl_reduce_multi_f32",
-           "csl_sage_rank_fwd_bwd_f32", "csl_sage_rank_workspace", "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch"]
+           "csl_sage_rank_fwd_bwd_f32", "csl_sage_rank_workspace", "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch",
+           "csl_gat_bwd_t_f32"]
 _ready = False
 
 
@@ -70,6 +71,7 @@ def _lib():
         L.csl_sage_rank_fwd_bwd_f32.argtypes = [i32, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, f32, i64, i32, EXCHANGE_FN,
                                                 EXCHANGE_WAIT_FN, vp, vp, vp, vp, i64, vp]
         L.csl_gat_logits_bwd_acc_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp]
+        L.csl_gat_bwd_t_f32.argtypes = [vp, vp, i64, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
         L.csl_gat_finish_fwd_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
         L.csl_gat_finish_bwd_f32.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]
         L.csl_gat_finish_bwd_scratch.argtypes = [i64, i32, i32]
@@ -656,7 +658,7 @@ class GatLayerLocal(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, attn_l, attn_r, bias, indptr, indices, self_ids_in, n_out, slope, elu, row_pad,
-                weight_grad):
+                weight_grad, t_indptr=None, t_indices=None):
         H, D = attn_l.shape
         Cw = H * D
         n_in, mp = x.shape[0], x.shape[0]
@@ -690,6 +692,10 @@ class GatLayerLocal(torch.autograd.Function):
              "csl_gat_finish_fwd_f32")
         ctx.save_for_backward(xp, weight, al, ar, z, el, er_out, m, s, n, out, indptr, indices, self_ids_in)
         ctx.cfg = (n_in, n_out, H, D, slope, bool(elu), weight_grad)
+        # the slice by source (engine flags FLAG_TRANSPOSE | FLAG_TRANSPOSE_ALL): the backward then writes the gradient
+        # of z row by row instead of scattering it with atomics into a zeroed buffer
+        ctx.by_source = ((_i32(t_indptr), _i32(t_indices)) if t_indptr is not None and t_indptr.numel() == n_in + 1
+                         else None)
         return out
 
     @staticmethod
@@ -710,12 +716,20 @@ class GatLayerLocal(torch.autograd.Function):
         scratch = C.c_void_p(buf.data_ptr() + 12 * Cw)
         _chk(L.csl_gat_finish_bwd_f32(_p(g), g.stride(0), _p(out), _p(n), _p(s), n_out, H, D, 1 if elu else 0, _p(g_n),
                                       _p(g_s), _p(g_bias), scratch, _stream()), "csl_gat_finish_bwd_f32")
-        # ONE gradient buffer for z (padded like the GEMM operand): the aggregation's atomics, then the logits' share
-        g_z = torch.zeros((z.shape[0], Cw), dtype=torch.float32, device=dev)
-        g_el = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
-        g_er_out = torch.empty((n_out, H), dtype=torch.float32, device=dev)
-        _chk(L.csl_gat_bwd_f32(_p(indptr), _p(indices), n_out, _p(el), _p(er_out), _p(z), H, D, slope, _p(m), _p(g_s),
-                               _p(g_n), _p(g_el), _p(g_er_out), _p(g_z), _stream()), "csl_gat_bwd_f32")
+        # ONE gradient buffer for z (padded like the GEMM operand): the aggregation's share, then the logits' share
+        if ctx.by_source is not None:
+            tptr, trow = ctx.by_source
+            g_z = torch.empty((z.shape[0], Cw), dtype=torch.float32, device=dev)     # every row is written
+            g_el = torch.empty((n_in, H), dtype=torch.float32, device=dev)
+            g_er_out = torch.zeros((n_out, H), dtype=torch.float32, device=dev)
+            _chk(L.csl_gat_bwd_t_f32(_p(tptr), _p(trow), n_in, z.shape[0], _p(el), _p(er_out), _p(z), H, D, slope, _p(m),
+                                     _p(g_s), _p(g_n), _p(g_el), _p(g_er_out), _p(g_z), _stream()), "csl_gat_bwd_t_f32")
+        else:
+            g_z = torch.zeros((z.shape[0], Cw), dtype=torch.float32, device=dev)
+            g_el = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
+            g_er_out = torch.empty((n_out, H), dtype=torch.float32, device=dev)
+            _chk(L.csl_gat_bwd_f32(_p(indptr), _p(indices), n_out, _p(el), _p(er_out), _p(z), H, D, slope, _p(m), _p(g_s),
+                                   _p(g_n), _p(g_el), _p(g_er_out), _p(g_z), _stream()), "csl_gat_bwd_f32")
         g_er = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
         scatter_add_rows_(g_er, self_ids_in, g_er_out)              # (a node is the self source of one destination)
         _chk(L.csl_gat_logits_bwd_acc_f32(_p(z), _p(al), _p(ar), _p(g_el), _p(g_er), n_in, H, D, _p(g_z), 1,
@@ -723,7 +737,7 @@ class GatLayerLocal(torch.autograd.Function):
              "csl_gat_logits_bwd_acc_f32")
         gw = weight_grad(g_z, xp)
         gx = (g_z @ weight)[:n_in] if ctx.needs_input_grad[0] else None
-        return gx, gw, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None
+        return gx, gw, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None
 
 
 def attention_gather(indptr, indices, u_in, v_in, n_rows):

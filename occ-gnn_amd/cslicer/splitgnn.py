@@ -483,7 +483,7 @@ class DistGATConv(nn.Module):
             g = parts[0]
             return {g: aggr.GatLayerLocal.apply(x[g], self.fc.weight, self.attn_l, self.attn_r, self.bias, sl[g].indptr,
                                                 sl[g].indices, sl[g].self_ids_in, sl[g].n_out, self.slope, bool(elu),
-                                                ROW_PAD, _weight_grad)}
+                                                ROW_PAD, _weight_grad, sl[g].t_indptr, sl[g].t_indices)}
         out = self._forward_parts(sl, x)
         return {g: torch.nn.functional.elu(v) for g, v in out.items()} if elu else out
 

@@ -57,10 +57,14 @@ class Trainer(object):
         import os
         by_source = (not self.rank_path and self.P == 1 and model == "sage" and len(fanouts) > 1
                      and not os.environ.get("CSLICER_NO_TRANSPOSE"))
+        eng_flags = _abi.FLAG_TRANSPOSE if by_source else 0
+        if (not self.rank_path and self.P == 1 and model == "gat" and not os.environ.get("CSLICER_NO_TRANSPOSE")):
+            # GAT aggregates PROJECTED features: every layer's sources take a gradient, the deepest layer's too
+            eng_flags = _abi.FLAG_TRANSPOSE | _abi.FLAG_TRANSPOSE_ALL
         self.eng = _abi.Engine(indptr, indices, n_parts=self.P, fanouts=fanouts, max_batch=batch,
                                n_streams=streams, n_slots=self.SLOTS, device=device, mode=_abi.MODE_GRAPH,
                                workload=workload, part_mask=(1 << rank) if self.rank_path else 0,
-                               flags=_abi.FLAG_TRANSPOSE if by_source else 0)
+                               flags=eng_flags)
         if workload is None:
             own = np.arange(rank, N, self.P, dtype=np.int64)           # owner v % P holds v at local row v // P
         else:

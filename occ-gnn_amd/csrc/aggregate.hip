@@ -313,6 +313,61 @@ __global__ __launch_bounds__(BLK) void k_gat_bwd(const int* __restrict__ indptr,
   }
 }
 
+// The same backward BY SOURCE (the slicer's CSL_T_INDPTR / CSL_T_INDICES, CSL_FLAG_TRANSPOSE_ALL): one wave per source
+// row u walks the destinations of its edges, so g_z[u, :] and g_el[u, :] are accumulated in registers and WRITTEN once --
+// no zero fill of the 0.7 GB gradient of z, no fp32 atomics on it; what is left to atomics is g_er (H floats per edge
+// instead of H * D; the caller zeroes it).  Rows [n_src, n_pad) of g_z are zeroed (GEMM operand padding).
+__global__ __launch_bounds__(BLK) void k_gat_bwd_t(const int* __restrict__ tptr, const int* __restrict__ trow,
+                                                   long long n_src, long long n_pad, const float* __restrict__ el,
+                                                   const float* __restrict__ er, const float* __restrict__ z, int H, int D,
+                                                   float slope, const float* __restrict__ m_in,
+                                                   const float* __restrict__ g_s, const float* __restrict__ g_n,
+                                                   float* __restrict__ g_el, float* g_er, float* __restrict__ g_z) {
+  const int lane = threadIdx.x & 63;
+  const long long u = (long long)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6);
+  if (u >= n_pad) return;
+  const int C = H * D, gsz = D / 4, lpc = (64 / gsz) * gsz, gl = lane % gsz;
+  const int j0 = u < n_src ? tptr[u] : 0, j1 = u < n_src ? tptr[u + 1] : 0;
+  for (int c0 = 0; c0 < C; c0 += lpc * 4) {
+    const int c = c0 + lane * 4;
+    const bool on = lane < lpc && c < C;
+    const int h = on ? c / D : 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), zv = acc;
+    float elu = 0.f, gel = 0.f;
+    if (u < n_src) {
+      elu = el[u * H + h];
+      if (on) zv = *reinterpret_cast<const float4*>(z + u * C + c);
+    }
+    for (int j = j0; j < j1; j++) {
+      const int r = trow[j];  // (wave-uniform)
+      if (r < 0) continue;    // the node's self entry: attention runs over the sampled edges only
+      const float raw = elu + er[(long long)r * H + h];
+      const float p = expf(leaky(raw, slope) - m_in[(long long)r * H + h]);
+      float dot = 0.f;
+      float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (on) {
+        gn = *reinterpret_cast<const float4*>(g_n + (long long)r * C + c);
+        dot = gn.x * zv.x + gn.y * zv.y + gn.z * zv.z + gn.w * zv.w;
+      }
+      for (int o = 1; o < gsz; o <<= 1) {  // sum over the head's lane group
+        const float t = __shfl_down(dot, o);
+        if (gl + o < gsz) dot += t;
+      }
+      dot = __shfl(dot, lane - gl);
+      const float gsc = (g_s[(long long)r * H + h] + dot) * p * (raw > 0.f ? 1.f : slope);
+      acc.x += p * gn.x, acc.y += p * gn.y, acc.z += p * gn.z, acc.w += p * gn.w;
+      if (on && c % D == 0) {
+        gel += gsc;
+        atomicAdd(g_er + (long long)r * H + h, gsc);
+      }
+    }
+    if (on) {
+      *reinterpret_cast<float4*>(g_z + u * C + c) = acc;
+      if (u < n_src && c % D == 0) g_el[u * H + h] = gel;
+    }
+  }
+}
+
 // ---- fused GraphSAGE layer pieces (one part per GPU and the single-GPU trainer) --------------------------
 // k_sage_cat: builds the operand of Linear(2*in, out) in ONE pass (dist_sageconv.py:66-80: self_gather, gather,
 // slice_owned_nodes, mean, concat):
@@ -941,6 +996,19 @@ int csl_spmm_sum_compact_f32(const int32_t* indptr, const int32_t* indices, cons
 
 // gradient of csl_sage_cat_f32's merged-sums form: gx [n_x, H] and gagg [n_agg, H] are zeroed here, then
 // gx[self_ids[r]] = gcat[r, 0:H) and gagg[owned[r]] = gcat[r, H:2H) / max(deg[r], 1) (both index lists are unique)
+int csl_gat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, int64_t n_src, int64_t n_pad, const float* el,
+                      const float* er, const float* z, int32_t H, int32_t D, float slope, const float* m_in,
+                      const float* g_s, const float* g_n, float* g_el, float* g_er, float* g_z, void* stream) {
+  if (n_src < 0 || n_pad < n_src || H < 1 || D < 4 || D % 4 != 0 || D > 256) return CSL_E_INVALID;
+  if (n_pad == 0) return CSL_OK;
+  if (!g_z || !aligned16(g_z) || (n_src > 0 && (!t_indptr || !el || !z || !g_el || !aligned16(z)))) return CSL_E_INVALID;
+  if (n_src > 0 && (!er || !m_in || !g_s || !g_n || !g_er || !aligned16(g_n))) return CSL_E_INVALID;
+  hipLaunchKernelGGL(k_gat_bwd_t, dim3((unsigned)((n_pad + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, (hipStream_t)stream,
+                     t_indptr, t_indices, (long long)n_src, (long long)n_pad, el, er, z, (int)H, (int)D, slope, m_in, g_s,
+                     g_n, g_el, g_er, g_z);
+  return done();
+}
+
 int csl_gat_finish_fwd_f32(const float* n_in, const float* s_in, const float* bias, int64_t n, int32_t H, int32_t D,
                            int32_t elu, float* out, void* stream) {
   if (n < 0 || H < 1 || D < 4 || D % 4 != 0 || D > 256) return CSL_E_INVALID;

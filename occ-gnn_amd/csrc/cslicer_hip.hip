@@ -1661,83 +1661,127 @@ __global__ __launch_bounds__(TN) void k_graph(LArgs a) {
 #undef TB
 }
 
-// ---- k_transpose (CSL_FLAG_TRANSPOSE): slice g of stream s by SOURCE, one block per (s, g).  k_graph left the number of
-// entries of every in node in tcur; here: exclusive scan -> t_indptr (tcur becomes the fill cursor), fill from the
-// slice's CSR and self lists (atomic cursors: any order), then every in node's short list is sorted, which makes the
-// result deterministic: ~r of the self entry first, then the out rows ascending.  A minibatch layer has ~10^5 entries:
-// one block per slice keeps this at one launch per layer, off the sampling chain's critical path.
-constexpr int TR_T = 1024;
-__global__ __launch_bounds__(TR_T) void k_transpose(LArgs a) {
-  const uint32_t s = blockIdx.x / a.P, g = blockIdx.x - s * a.P;
-  if (!((a.pmask >> g) & 1u)) return;
-  const uint32_t F = a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer];
-  if (F == 0) return;
+// ---- the slice by SOURCE (CSL_FLAG_TRANSPOSE).  k_graph left the number of entries of every in node of slice g of stream
+// s in tcur; four small grid-wide passes turn that into t_indptr / t_indices (one 1024-thread block per slice did all
+// of it in round 2's first version: 0.35 ms per launch for the trainer's middle layer, 4 ms for a deepest layer of 0.7 M
+// in nodes -- one CU per stream, a tenth of a GAT training step on the side stream):
+//   k_tsum   sum of every tile of TT in nodes                              grid (tiles, S * P)
+//   k_tptr   tile base = sum of the tile sums before it; exclusive scan inside the tile -> t_indptr, tcur := cursor
+//   k_tfill  every out row (and self entry) drops its row id at its source's cursor (atomic: any order)
+//   k_tsort  every in node's short list sorted -> deterministic: ~r of the self entry first, then the out rows ascending
+constexpr int TT = 2048;  // in nodes per tile: 8 per thread
+struct TSlice {
+  uint32_t n_in, n_out, n_self;
+  uint32_t* cnt;
+  int* tptr;
+  int* trow;
+  const int *indptr, *indices, *self_in, *self_out;
+};
+__device__ __forceinline__ bool tslice(const LArgs& a, TSlice& t, uint32_t& s, uint32_t& g) {
+  s = blockIdx.y / a.P, g = blockIdx.y - s * a.P;
+  if (!((a.pmask >> g) & 1u)) return false;
+  if (a.fsize[s * (CSL_MAX_LAYERS + 1) + a.layer] == 0) return false;
   const csl_layer_meta& m = a.meta[s].layer[a.layer];
   int* ar = a.arena + (size_t)s * a.arena_stride;
-  const uint32_t n_in = m.off[CSL_IN_NODES][g + 1] - m.off[CSL_IN_NODES][g];
-  const uint32_t n_out = m.off[CSL_OUT_NODES][g + 1] - m.off[CSL_OUT_NODES][g];
-  const uint32_t n_self = m.off[CSL_SELF_IDS_IN][g + 1] - m.off[CSL_SELF_IDS_IN][g];
-  uint32_t* cnt = a.tcur + (size_t)s * a.ccap + m.off[CSL_IN_NODES][g];
-  int* tptr = ar + a.list_base[CSL_T_INDPTR] + m.off[CSL_T_INDPTR][g];
-  int* trow = ar + a.list_base[CSL_T_INDICES] + m.off[CSL_T_INDICES][g];
-  const int* indptr = ar + a.list_base[CSL_INDPTR] + m.off[CSL_INDPTR][g];
-  const int* indices = ar + a.list_base[CSL_INDICES] + m.off[CSL_INDICES][g];
-  const int* self_in = ar + a.list_base[CSL_SELF_IDS_IN] + m.off[CSL_SELF_IDS_IN][g];
-  const int* self_out = ar + a.list_base[CSL_SELF_IDS_OUT] + m.off[CSL_SELF_IDS_OUT][g];
-  __shared__ uint32_t s_w[TR_T / 64];
-  __shared__ uint32_t s_total;
-  const uint32_t t = threadIdx.x, w = t >> 6;
-  // exclusive scan, a contiguous chunk per thread
-  const uint32_t chunk = (n_in + TR_T - 1) / TR_T;
-  const uint32_t lo = t * chunk < n_in ? t * chunk : n_in;
-  const uint32_t hi = lo + chunk < n_in ? lo + chunk : n_in;
-  uint32_t sum = 0;
-  for (uint32_t u = lo; u < hi; u++) sum += cnt[u];
+  t.n_in = m.off[CSL_IN_NODES][g + 1] - m.off[CSL_IN_NODES][g];
+  t.n_out = m.off[CSL_OUT_NODES][g + 1] - m.off[CSL_OUT_NODES][g];
+  t.n_self = m.off[CSL_SELF_IDS_IN][g + 1] - m.off[CSL_SELF_IDS_IN][g];
+  t.cnt = a.tcur + (size_t)s * a.ccap + m.off[CSL_IN_NODES][g];
+  t.tptr = ar + a.list_base[CSL_T_INDPTR] + m.off[CSL_T_INDPTR][g];
+  t.trow = ar + a.list_base[CSL_T_INDICES] + m.off[CSL_T_INDICES][g];
+  t.indptr = ar + a.list_base[CSL_INDPTR] + m.off[CSL_INDPTR][g];
+  t.indices = ar + a.list_base[CSL_INDICES] + m.off[CSL_INDICES][g];
+  t.self_in = ar + a.list_base[CSL_SELF_IDS_IN] + m.off[CSL_SELF_IDS_IN][g];
+  t.self_out = ar + a.list_base[CSL_SELF_IDS_OUT] + m.off[CSL_SELF_IDS_OUT][g];
+  return true;
+}
+__device__ __forceinline__ uint32_t block_sum(uint32_t x, uint32_t* s_w) {  // 256 threads
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+  if (lane_id() == 0) s_w[threadIdx.x >> 6] = x;
+  __syncthreads();
+  const uint32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  __syncthreads();
+  return tot;
+}
+__global__ __launch_bounds__(TN) void k_tsum(LArgs a, uint32_t* __restrict__ tsum, uint32_t ttiles) {
+  TSlice t;
+  uint32_t s, g;
+  if (!tslice(a, t, s, g) || blockIdx.x * TT >= t.n_in) return;
+  __shared__ uint32_t s_w[NW];
+  const uint32_t u0 = blockIdx.x * TT + threadIdx.x * 8;
+  uint32_t x = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) x += u0 + k < t.n_in ? t.cnt[u0 + k] : 0u;
+  const uint32_t tot = block_sum(x, s_w);
+  if (threadIdx.x == 0) tsum[(size_t)blockIdx.y * ttiles + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(TN) void k_tptr(LArgs a, const uint32_t* __restrict__ tsum, uint32_t ttiles) {
+  TSlice t;
+  uint32_t s, g;
+  if (!tslice(a, t, s, g)) return;
+  if (t.n_in == 0) {  // a part without a node in this layer: its row pointers are the single 0
+    if (blockIdx.x == 0 && threadIdx.x == 0) t.tptr[0] = 0;
+    return;
+  }
+  if (blockIdx.x * TT >= t.n_in) return;
+  __shared__ uint32_t s_w[NW];
+  const uint32_t* ts = tsum + (size_t)blockIdx.y * ttiles;
+  uint32_t before = 0;
+  for (uint32_t k = threadIdx.x; k < blockIdx.x; k += TN) before += ts[k];
+  const uint32_t base = block_sum(before, s_w);
+  const uint32_t u0 = blockIdx.x * TT + threadIdx.x * 8;
+  uint32_t c[8], x = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    c[k] = u0 + k < t.n_in ? t.cnt[u0 + k] : 0u;
+    x += c[k];
+  }
   uint32_t wtot;
-  uint32_t run = wave_excl_scan(sum, wtot);
-  if (lane_id() == 0) s_w[w] = wtot;
+  uint32_t run = wave_excl_scan(x, wtot);
+  if (lane_id() == 0) s_w[threadIdx.x >> 6] = wtot;
   __syncthreads();
-  if (t == 0) {
-    uint32_t r = 0;
-    for (int k = 0; k < TR_T / 64; k++) {
-      const uint32_t x = s_w[k];
-      s_w[k] = r;
-      r += x;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) run += s_w[w];
+  run += base;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (u0 + k < t.n_in) {
+      t.tptr[u0 + k] = (int)run;
+      t.cnt[u0 + k] = run;  // the fill cursor
     }
-    s_total = r;
+    run += c[k];
   }
-  __syncthreads();
-  run += s_w[w];
-  for (uint32_t u = lo; u < hi; u++) {
-    const uint32_t c = cnt[u];
-    tptr[u] = (int)run;
-    cnt[u] = run;
-    run += c;
+  // the slice's last in node closes the row pointers
+  if (u0 <= t.n_in - 1 && t.n_in - 1 < u0 + 8) t.tptr[t.n_in] = (int)run;
+}
+__global__ __launch_bounds__(TN) void k_tfill(LArgs a) {
+  TSlice t;
+  uint32_t s, g;
+  if (!tslice(a, t, s, g)) return;
+  const uint32_t r = blockIdx.x * TN + threadIdx.x;
+  if (r < t.n_self) {
+    const int u = t.self_in[r];
+    if (u >= 0) t.trow[atomicAdd(&t.cnt[u], 1u)] = ~t.self_out[r];
   }
-  if (t == 0) tptr[n_in] = (int)s_total;
-  __syncthreads();  // (block-scope visibility of the cursors)
-  // fill
-  for (uint32_t k = t; k < n_self; k += TR_T) {
-    const int u = self_in[k];
-    if (u >= 0) trow[atomicAdd(&cnt[u], 1u)] = ~self_out[k];
+  if (r < t.n_out) {
+    const int e1 = t.indptr[r + 1];
+    for (int e = t.indptr[r]; e < e1; e++) t.trow[atomicAdd(&t.cnt[t.indices[e]], 1u)] = (int)r;
   }
-  for (uint32_t r = t; r < n_out; r += TR_T) {
-    const int e1 = indptr[r + 1];
-    for (int e = indptr[r]; e < e1; e++) trow[atomicAdd(&cnt[indices[e]], 1u)] = (int)r;
-  }
-  __syncthreads();
-  // sort every in node's entries (insertion sort: lists hold one or two entries on average)
-  for (uint32_t u = t; u < n_in; u += TR_T) {
-    const int j0 = tptr[u], j1 = tptr[u + 1];
-    for (int j = j0 + 1; j < j1; j++) {
-      const int x = trow[j];
-      int k = j - 1;
-      while (k >= j0 && trow[k] > x) {
-        trow[k + 1] = trow[k];
-        k--;
-      }
-      trow[k + 1] = x;
+}
+__global__ __launch_bounds__(TN) void k_tsort(LArgs a) {
+  TSlice t;
+  uint32_t s, g;
+  if (!tslice(a, t, s, g)) return;
+  const uint32_t u = blockIdx.x * TN + threadIdx.x;
+  if (u >= t.n_in) return;
+  const int j0 = t.tptr[u], j1 = t.tptr[u + 1];
+  for (int j = j0 + 1; j < j1; j++) {  // insertion sort: one or two entries on average
+    const int x = t.trow[j];
+    int k = j - 1;
+    while (k >= j0 && t.trow[k] > x) {
+      t.trow[k + 1] = t.trow[k];
+      k--;
     }
+    t.trow[k + 1] = x;
   }
 }
 
@@ -1999,6 +2043,8 @@ struct csl_engine {
   uint8_t* ecnt = nullptr;
   uint32_t* srcpos = nullptr;
   uint32_t* tcur = nullptr;
+  uint32_t* tsum = nullptr;     // CSL_FLAG_TRANSPOSE: [nsets][S][P][ttiles_max] in-node tile sums
+  size_t ttiles_max = 0;
   uint32_t* dupflag = nullptr;   // [nsets][S]
   uint32_t* seedrep = nullptr;   // [nsets][S][fcap0]
   uint32_t* dupfirst = nullptr;  // [nsets][S][fcap0*P]
@@ -2332,7 +2378,7 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     a.graph = e->cfg.mode == CSL_MODE_GRAPH ? 1u : 0u;
     a.ecnt = e->ecnt ? e->ecnt + sF * e->P : nullptr;
     a.srcpos = e->srcpos ? e->srcpos + sC : nullptr;
-    a.tcur = (e->tcur && l < L - 1) ? e->tcur + sC : nullptr;
+    a.tcur = (e->tcur && (l < L - 1 || (e->cfg.flags & CSL_FLAG_TRANSPOSE_ALL))) ? e->tcur + sC : nullptr;
     a.dupflag = e->dupflag + (size_t)set * S;
     a.fcap0 = e->fcap[0];
     a.seedrep = e->seedrep + (size_t)set * S * e->fcap[0];
@@ -2427,7 +2473,17 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
       hipLaunchKernelGGL(k_selfin, dim3(n_selfin), blk, 0, st, a);
     }
     // (after k_selfin: the self entries come from self_ids_in)
-    if (a.tcur) hipLaunchKernelGGL(k_transpose, dim3((unsigned)(S * e->P)), dim3(TR_T), 0, st, a);
+    if (a.tcur) {
+      const unsigned sp = (unsigned)(S * e->P);
+      const unsigned in_cap = (unsigned)ccap_l;  // in nodes of a slice <= candidates of the layer
+      const unsigned ttiles = (in_cap + TT - 1) / TT;
+      uint32_t* tsum = e->tsum + (size_t)set * S * e->P * e->ttiles_max;
+      hipLaunchKernelGGL(k_tsum, dim3(ttiles, sp), blk, 0, st, a, tsum, (uint32_t)e->ttiles_max);
+      hipLaunchKernelGGL(k_tptr, dim3(ttiles, sp), blk, 0, st, a, (const uint32_t*)tsum, (uint32_t)e->ttiles_max);
+      // (a slice has at most list_cap[OUT_NODES] out rows, and no more self entries than that)
+      hipLaunchKernelGGL(k_tfill, dim3((unsigned)((e->list_cap[l][CSL_OUT_NODES] + TN - 1) / TN), sp), blk, 0, st, a);
+      hipLaunchKernelGGL(k_tsort, dim3((in_cap + TN - 1) / TN, sp), blk, 0, st, a);
+    }
   }
   HIPCHECK(hipGetLastError());
   for (int s = 0; s < n_batches && s < S; s++) e->pos_ub[s] += e->worst_draws;
@@ -2461,7 +2517,7 @@ void csl_destroy(csl_engine* e) {
   void* ptrs[] = {e->rowinfo, e->off32, e->indices, e->wl,      e->nodes, e->seedbuf, e->ring,  e->mt_state, e->rngpos,
                   e->rngbase, e->ninfo,   e->hasedge, e->selfpos, e->firstpos, e->cand, e->cflag, e->crank,
                   e->queue,   e->nbk,     e->bcnt,    e->bcur,    e->tcnt,     e->fsize, e->meta, e->desc_dev,
-                  e->ecnt,    e->srcpos,  e->tcur, e->acc,     e->dupflag, e->seedrep, e->dupfirst, e->dupout, e->rngend,
+                  e->ecnt,    e->srcpos,  e->tcur, e->tsum, e->acc,     e->dupflag, e->seedrep, e->dupfirst, e->dupout, e->rngend,
                   e->candk,   e->boff,    e->ticket};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -2572,7 +2628,11 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
   if (cfg->mode == CSL_MODE_GRAPH) {
     DMALLOC(e->ecnt, e->nsets * (size_t)S * e->fcap_max * P);
     DMALLOC(e->srcpos, e->nsets * (size_t)S * e->ccap_max);
-    if ((cfg->flags & CSL_FLAG_TRANSPOSE) && L > 1) DMALLOC(e->tcur, e->nsets * (size_t)S * e->ccap_max);
+    if ((cfg->flags & CSL_FLAG_TRANSPOSE) && (L > 1 || (cfg->flags & CSL_FLAG_TRANSPOSE_ALL))) {
+      DMALLOC(e->tcur, e->nsets * (size_t)S * e->ccap_max);
+      e->ttiles_max = (e->ccap_max + TT - 1) / TT;
+      DMALLOC(e->tsum, e->nsets * (size_t)S * P * e->ttiles_max);
+    }
   }
   DMALLOC(e->queue, e->nsets * (size_t)S * e->ccap_max);
   DMALLOC(e->dupflag, e->nsets * (size_t)S);
@@ -2634,7 +2694,7 @@ static int create_impl(const csl_config* cfg, csl_engine* e) {
       cap[CSL_INDPTR] = outs_g + (size_t)P;
       cap[CSL_INDICES] = edges;
       cap[CSL_OWNED_DEGREE] = F;
-      if ((cfg->flags & CSL_FLAG_TRANSPOSE) && l < L - 1) {
+      if ((cfg->flags & CSL_FLAG_TRANSPOSE) && (l < L - 1 || (cfg->flags & CSL_FLAG_TRANSPOSE_ALL))) {
         cap[CSL_T_INDPTR] = edges + F + (size_t)P;
         cap[CSL_T_INDICES] = edges + F;
       }
@@ -2695,6 +2755,8 @@ int csl_create(const csl_config* cfg, csl_engine** out) {
   if (cfg->mode != CSL_MODE_STRICT && cfg->mode != CSL_MODE_GRAPH) return fail(CSL_E_INVALID, "unknown mode %d", cfg->mode);
   if ((cfg->flags & CSL_FLAG_TRANSPOSE) && cfg->mode != CSL_MODE_GRAPH)
     return fail(CSL_E_INVALID, "CSL_FLAG_TRANSPOSE needs CSL_MODE_GRAPH (strict mode has no edges to transpose)");
+  if ((cfg->flags & CSL_FLAG_TRANSPOSE_ALL) && !(cfg->flags & CSL_FLAG_TRANSPOSE))
+    return fail(CSL_E_INVALID, "CSL_FLAG_TRANSPOSE_ALL only widens CSL_FLAG_TRANSPOSE");
   if (cfg->part_mask >> cfg->n_parts) return fail(CSL_E_INVALID, "part_mask 0x%x names parts beyond n_parts", cfg->part_mask);
   if (!cfg->indptr || (!cfg->indices && cfg->num_edges > 0)) return fail(CSL_E_INVALID, "graph arrays missing");
   // the reference keeps ids in `int` (bipartite.h:55): node ids are only defined below 2^31.  Row offsets:

@@ -162,8 +162,9 @@ def _dense_gat_vectorised(model, trav, feats):
     return h
 
 
+@pytest.mark.parametrize("by_source", [False, True])
 @pytest.mark.parametrize("heads,hidden,B", [(8, 32, 256), (2, 12, 64), (3, 8, 700)])
-def test_fused_local_gat_layer_matches_the_node_by_node_path(mods, heads, hidden, B, monkeypatch):
+def test_fused_local_gat_layer_matches_the_node_by_node_path(mods, heads, hidden, B, by_source, monkeypatch):
     """aggr.GatLayerLocal (a whole layer + ELU as one autograd node: epilogue kernels, one gradient buffer for z)
     against the same model through the separate autograd nodes (CSLICER_NO_LOCAL_FUSE): logits, every parameter
     gradient and the input gradient."""
@@ -172,9 +173,13 @@ def test_fused_local_gat_layer_matches_the_node_by_node_path(mods, heads, hidden
     torch.manual_seed(heads)
     n, F0, classes = 6000, 20, 7
     indptr, indices = l0.synth_graph(n, 12.0, seed=heads)
-    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(5, 4, 3), max_batch=B, mode=abi.MODE_GRAPH)
+    # by_source: the engine emits the slices by source for EVERY layer and the fused layer's backward writes the
+    # gradient of z row by row (csl_gat_bwd_t_f32) instead of scattering it with atomics (csl_gat_bwd_f32)
+    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(5, 4, 3), max_batch=B, mode=abi.MODE_GRAPH,
+                     flags=(abi.FLAG_TRANSPOSE | abi.FLAG_TRANSPOSE_ALL) if by_source else 0)
     eng.submit_seeds([np.random.default_rng(3).permutation(n)[:B]])
     slices = sg.slices_of(eng)
+    assert all(bool(slices[l][0].t_indptr.numel()) == by_source for l in range(3))
     monkeypatch.setattr(sg, "ROW_PAD", 512)          # both the padded and the unpadded GEMM operand occur
     model = sg.DistGATModel(F0, hidden, classes, heads=heads, n_layers=3).cuda()
     with torch.no_grad():

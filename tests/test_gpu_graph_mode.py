@@ -72,14 +72,15 @@ def check_graph_invariants(d, indptr, indices, P):
         assert sum(int(bp["owned_degree"].sum()) for bp in parts) == edges
 
 
-def check_transposed(d):
-    """FLAG_TRANSPOSE: t_indptr / t_indices of every layer but the deepest are the slice CSR + self lists sorted by
-    source (cslicer_hip.h, CSL_T_INDPTR): per in node ~r of its self entry, then the out rows of its edges ascending."""
+def check_transposed(d, deepest_too=False):
+    """FLAG_TRANSPOSE: t_indptr / t_indices of every layer but the deepest (FLAG_TRANSPOSE_ALL: of every layer) are the
+    slice CSR + self lists sorted by source (cslicer_hip.h, CSL_T_INDPTR): per in node ~r of its self entry, then the
+    out rows of its edges ascending."""
     L = len(d["layers"])
     for l, parts in enumerate(d["layers"]):
         for g, bp in enumerate(parts):
             tag = "layer %d part %d " % (l, g)
-            if l == L - 1:
+            if l == L - 1 and not deepest_too:
                 assert len(bp["t_indptr"]) == 0 and len(bp["t_indices"]) == 0, tag
                 continue
             n_in = len(bp["in_nodes"])
@@ -124,6 +125,24 @@ def test_graph_mode_matches_specification(abi, orc, cfg):
             assert got["draws_total"] == want["draws_total"]
             check_graph_invariants(got, indptr, indices, P)
             check_transposed(got)
+    e.close()
+
+
+def test_transpose_all_covers_the_deepest_layer(abi, orc):
+    from cslicer import l0
+    indptr, indices = l0.synth_graph(5000, 18.0, seed=8)
+    perm = np.random.default_rng(1).permutation(5000)
+    with pytest.raises(abi.CslError):
+        abi.Engine(indptr, indices, max_batch=64, mode=abi.MODE_GRAPH, flags=abi.FLAG_TRANSPOSE_ALL)   # widens TRANSPOSE only
+    e = abi.Engine(indptr, indices, n_parts=3, fanouts=(6, 5, 4), max_batch=200, n_streams=2, mode=abi.MODE_GRAPH,
+                   flags=abi.FLAG_TRANSPOSE | abi.FLAG_TRANSPOSE_ALL)
+    e.set_nodes(perm)
+    o = [orc.Oracle(indptr, indices, n_parts=3, fanouts=(6, 5, 4)) for _ in range(2)]
+    e.submit_round(0, 200, 2)
+    for s in range(2):
+        got = e.graph_dict(s)
+        assert_same_graph(got, o[s].sample_graph(perm[s * 200:(s + 1) * 200]), what="stream %d" % s)
+        check_transposed(got, deepest_too=True)
     e.close()
 
 
