@@ -1774,14 +1774,39 @@ __global__ __launch_bounds__(TN) void k_tsort(LArgs a) {
   const uint32_t u = blockIdx.x * TN + threadIdx.x;
   if (u >= t.n_in) return;
   const int j0 = t.tptr[u], j1 = t.tptr[u + 1];
-  for (int j = j0 + 1; j < j1; j++) {  // insertion sort: one or two entries on average
-    const int x = t.trow[j];
-    int k = j - 1;
-    while (k >= j0 && t.trow[k] > x) {
-      t.trow[k + 1] = t.trow[k];
-      k--;
+  int* v = t.trow + j0;
+  const int len = j1 - j0;
+  if (len <= 24) {
+    for (int j = 1; j < len; j++) {  // insertion sort: one or two entries on average
+      const int x = v[j];
+      int k = j - 1;
+      while (k >= 0 && v[k] > x) {
+        v[k + 1] = v[k];
+        k--;
+      }
+      v[k + 1] = x;
     }
-    t.trow[k + 1] = x;
+    return;
+  }
+  // a hub (a source that thousands of the minibatch's rows sampled): heap sort, O(len log len) whatever the order
+  auto sift = [&](int root, int end) {
+    const int x = v[root];
+    for (;;) {
+      int child = 2 * root + 1;
+      if (child >= end) break;
+      if (child + 1 < end && v[child + 1] > v[child]) child++;
+      if (v[child] <= x) break;
+      v[root] = v[child];
+      root = child;
+    }
+    v[root] = x;
+  };
+  for (int i = len / 2 - 1; i >= 0; i--) sift(i, len);
+  for (int end = len - 1; end > 0; end--) {
+    const int top = v[0];
+    v[0] = v[end];
+    v[end] = top;
+    sift(0, end);
   }
 }
 

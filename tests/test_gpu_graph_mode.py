@@ -146,6 +146,28 @@ def test_transpose_all_covers_the_deepest_layer(abi, orc):
     e.close()
 
 
+def test_slices_by_source_with_hub_nodes(abi, orc):
+    """Three hub nodes are neighbours of every node: each is the source of thousands of a minibatch's edges, i.e. its
+    list in the slice by source is thousands of entries long (sorted by the heap-sort path, walked by one wave)."""
+    n, deg = 30000, 12
+    rng = np.random.default_rng(4)
+    nb = rng.integers(0, n, size=(n, deg))
+    nb[:, :3] = np.array([7, 11, 13])                       # the hubs
+    nb[[7, 11, 13]] = rng.integers(100, n, size=(3, deg))   # (no self loops on them)
+    indptr = np.arange(n + 1, dtype=np.int64) * deg
+    indices = np.sort(nb, axis=1).reshape(-1).astype(np.int64)
+    seeds = rng.permutation(n)[:1024]
+    e = abi.Engine(indptr, indices, n_parts=2, fanouts=(8, 6), max_batch=1024, mode=abi.MODE_GRAPH,
+                   flags=abi.FLAG_TRANSPOSE | abi.FLAG_TRANSPOSE_ALL)
+    e.submit_seeds([seeds])
+    got = e.graph_dict(0)
+    assert_same_graph(got, orc.Oracle(indptr, indices, n_parts=2, fanouts=(8, 6)).sample_graph(seeds))
+    check_transposed(got, deepest_too=True)
+    longest = max(int(np.diff(bp["t_indptr"]).max()) for parts in got["layers"] for bp in parts if len(bp["t_indptr"]))
+    assert longest > 1000, longest
+    e.close()
+
+
 def test_transpose_flag_needs_graph_mode_and_is_off_by_default(abi):
     from cslicer import l0
     indptr, indices = l0.synth_graph(500, 8.0, seed=1)
