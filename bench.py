@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--e2e-steps", type=int, default=128,
                     help="end-to-end training minibatches for the secondary iters/s figure (0 = skip)")
     ap.add_argument("--no-e2e-multi", action="store_true", help="several GPUs: skip the split-parallel training leg")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short child runs of this workload under rocprofv3 "
+                         "--pmc FETCH_SIZE / WRITE_SIZE); the committed profiles/<LATEST>/pmc.json is then quoted instead")
     ap.add_argument("--e2e-overlap", action="store_true",
                     help="several GPUs: run every boundary exchange of the split-parallel step on a side HIP stream while the "
                          "rows that stay on the GPU are aggregated (same numbers; off by default until it can be measured on "
@@ -199,6 +202,50 @@ def compat_leg(indptr, indices, args, B, samples=384, workers=32):
             "config": "native pybind module `cslicer`, fanout 10/10/10, 4 parts (v %% 4), minibatch %d, host `long` "
                       "lists per sample (PCIe + deep copy inclusive)" % B,
             "in_nodes_of_last_sample": ids, "constructor_seconds": t_load}
+
+
+def live_pmc_traffic(args, kernel, rounds=8, warm=2, timeout=240):
+    """HBM-side traffic of `kernel`, bytes per launch, measured NOW: two child runs of this same workload under rocprofv3,
+    one per counter (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, each with --kernel-trace only: MI355X_MICROARCH.md's recipe),
+    rounds on one HIP stream.  FETCH_SIZE counts 64-B units of read requests that are all 128 B on this path
+    (profiles/pmc_rdsize.sh), hence 2 x FETCH_SIZE + WRITE_SIZE.  Returns (bytes per launch, launches) or raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise RuntimeError("rocprofv3 not found")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", str(rounds), "--warmup", str(warm), "--no-cpu-baseline",
+             "--no-compat", "--no-kernel-timing", "--no-live-pmc", "--serial-rounds", "--e2e-steps", "0", "--gpus", "1",
+             "--streams", str(args.streams), "--batch", str(args.batch), "--parts", str(args.parts), "--fanout", args.fanout,
+             "--nodes", str(args.nodes), "--mean-deg", str(args.mean_deg), "--graph-seed", str(args.graph_seed),
+             "--mode", args.mode]
+    if args.unsorted_rows:
+        child.append("--unsorted-rows")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = env.get("TMPDIR") or "/tmp"
+    tot = {}
+    with tempfile.TemporaryDirectory(prefix="bench_pmc_", dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + child,
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                raise RuntimeError("rocprofv3 wrote no counter file for " + counter)
+            kib, n = 0.0, 0
+            for r in csv.DictReader(open(files[0])):
+                nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                if nm == kernel and r["Counter_Name"] == counter:
+                    kib += float(r["Counter_Value"])
+                    n += 1
+            if n == 0:
+                raise RuntimeError("no launch of %s in the %s pass" % (kernel, counter))
+            tot[counter] = (kib, n)
+    n = tot["FETCH_SIZE"][1]
+    return 1024.0 * (2.0 * tot["FETCH_SIZE"][0] / n + tot["WRITE_SIZE"][0] / tot["WRITE_SIZE"][1]), n
 
 
 def launch_plan(gpus, env):
@@ -585,6 +632,7 @@ def main():
                           "hidden %d, classes %d, fp32, Adam" % ("/".join(map(str, fan)), B, (B + world - 1) // world,
                                                                  world, args.e2e_feat, args.e2e_hidden, args.e2e_classes)}
 
+    live_pmc_kernel = None
     if rank == 0:
         # ---- per-kernel HIP-event timing pass (engine's own stream) for the roofline
         if not args.no_kernel_timing:
@@ -639,6 +687,7 @@ def main():
                 pass
             out["kernels"] = per_kernel
             out["timing_pass_ms_per_step"] = 1e3 * t_ev / args.steps
+            live_pmc_kernel = dom
         # whole path against the HBM roof, SURVEY 8(d) byte formula (reference data types)
         per_iter = [{k: v / S for k, v in d.items()} for d in stats]
         pb = path_bytes_reference_types(per_iter, P)
@@ -707,6 +756,18 @@ def main():
     if eng is not None:
         eng.close()
         eng = None
+    if rank == 0 and world == 1 and live_pmc_kernel and not args.no_live_pmc:
+        # roofline.traffic measured in THIS run (the engine above is closed: the children get the GPU's memory)
+        try:
+            name = "k_bucket<false>" if live_pmc_kernel == "k_bucket" else live_pmc_kernel   # (no workload table here)
+            traffic, launches = live_pmc_traffic(args, name)
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_source"] = (
+                "measured in this run: two child runs of this workload under rocprofv3 (--pmc FETCH_SIZE, --pmc WRITE_SIZE; "
+                "%d launches each), 2 x FETCH_SIZE + WRITE_SIZE (every read request of this path is 128 B: "
+                "profiles/pmc_rdsize.sh)" % launches)
+        except Exception as ex:   # the committed PMC summary quoted above stays
+            out["roofline"]["traffic_live_error"] = repr(ex)[:200]
     if rank == 0 and world == 1 and not args.no_compat:
         try:
             out["compat_path"] = compat_leg(indptr, indices, args, B)
