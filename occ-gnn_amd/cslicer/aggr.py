@@ -364,6 +364,8 @@ class SageStep(object):
         for k, s in enumerate(slices):
             c = self._sl[k]
             c.indptr, c.indices, c.self_ids_in = s.ptr(A.INDPTR), s.ptr(A.INDICES), s.ptr(A.SELF_IDS_IN)
+            if k and s.count(A.T_INDPTR) != s.n_in + 1:
+                raise ValueError("layer %d has no slice by source: create the engine with flags=FLAG_TRANSPOSE" % k)
             c.t_indptr, c.t_indices = (s.ptr(A.T_INDPTR), s.ptr(A.T_INDICES)) if k else (None, None)
             c.n_out, c.n_in = s.n_out, s.n_in
         L = _lib()

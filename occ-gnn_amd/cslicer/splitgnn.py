@@ -70,6 +70,10 @@ class Slice(object):
         """device address of the part's list of `kind` (an _abi list kind) inside the engine's arena"""
         return self._t.data_ptr() + 4 * (self._origin + self._lbase[kind] + int(self._lm.off[kind][self.part]))
 
+    def count(self, kind):
+        """entries of the part's list of `kind`"""
+        return int(self._lm.off[kind][self.part + 1]) - int(self._lm.off[kind][self.part])
+
     def __getattr__(self, name):          # only reached for a list that has not been made yet
         lm, g = self._lm, self.part
         kind = _SLICE_LISTS.get(name)

@@ -391,6 +391,14 @@ def test_native_step_matches_the_autograd_path(mods, B, row_pad):
     want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     step = aggr.SageStep(model, row_pad, 4)
     got_loss = torch.zeros(1, device="cuda")
+    if B == 128 and row_pad == 0:
+        # slices of an engine WITHOUT the slices by source are refused, not read as garbage
+        e2 = abi.Engine(indptr, indices, n_parts=1, fanouts=(6, 5, 4), max_batch=B, mode=abi.MODE_GRAPH)
+        e2.submit_seeds([np.random.default_rng(3).permutation(n)[:B]])
+        s2 = sg.slices_of(e2)
+        with pytest.raises(ValueError):
+            step([s2[2][0], s2[1][0], s2[0][0]], feats, labels, 1.0 / B, got_loss)
+        e2.close()
     for _ in range(2):   # the second call reuses workspace and GEMM plans
         step([slices[2][0], slices[1][0], slices[0][0]], feats, labels, 1.0 / B, got_loss)
         torch.testing.assert_close(got_loss[0], loss.detach(), rtol=1e-5, atol=1e-6)
