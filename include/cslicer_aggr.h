@@ -241,6 +241,9 @@ typedef struct {
   const int32_t* t_indices;
   int64_t n_out;
   int64_t n_in;
+  /* csl_layer_meta.t_max_len of the slice: above CSL_T_SORTED_MAX (a hub node's list: one wave would walk thousands of
+   * entries) the layer's input gradient is scattered with atomics (csl_sage_cat_bwd_f32) instead of gathered */
+  int64_t t_max_len;
 } csl_sage_slice;
 int64_t csl_sage_fwd_bwd_workspace(int32_t n_layers, const int32_t* dims, const csl_sage_slice* slices, int64_t row_pad,
                                    int32_t n_slabs);

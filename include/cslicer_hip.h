@@ -37,7 +37,7 @@ extern "C" {
 
 #define CSL_MAX_PARTS 8
 #define CSL_MAX_LAYERS 4
-#define CSL_ABI_VERSION 4
+#define CSL_ABI_VERSION 5
 
 enum {
   CSL_OK = 0,
@@ -81,10 +81,16 @@ enum {
    * aggregation as a gather (each source-gradient row written once: no atomics, nothing to pre-zero).
    * For in node u of slice g, entries [t_indptr[u], t_indptr[u+1]) of t_indices hold, ascending: ~r (negative) when u
    * is the self source of owned out node r (self_ids_in/self_ids_out), then the out row r of every edge u -> r of the
-   * slice's CSR (a row twice when the edge was sampled twice). */
+   * slice's CSR (a row twice when the edge was sampled twice).  Lists longer than CSL_T_SORTED_MAX entries -- hub nodes
+   * that thousands of the minibatch's rows sampled -- hold the same entries in UNSPECIFIED order;
+   * csl_layer_meta.t_max_len tells a consumer whether a slice has such a list (a gather over one of them is one
+   * wave's serial walk: consumers fall back to their scatter form for that layer). */
   CSL_T_INDPTR = 10,        /* len(in_nodes)+1 per part */
   CSL_T_INDICES = 11,       /* len(indices) + len(self_ids_in) per part */
   CSL_NUM_LISTS = 12
+};
+enum {
+  CSL_T_SORTED_MAX = 128    /* longest list of a slice by source that is sorted */
 };
 
 /* csl_config.mode */
@@ -164,6 +170,8 @@ typedef struct {
    * reorder() does not deduplicate.  Equals len(out_nodes) unless the minibatch repeats a seed id (layer 0).
    * graph mode: len(out_nodes) + 1 when the layer is not empty (the CSR row pointers). */
   uint32_t indptr_len[CSL_MAX_PARTS];
+  /* CSL_FLAG_TRANSPOSE: length of the longest list of slice g by source (0 without the flag) */
+  uint32_t t_max_len[CSL_MAX_PARTS];
 } csl_layer_meta;
 
 typedef struct {

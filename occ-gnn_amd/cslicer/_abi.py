@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CSLICER_LIB") or os.path.join(os.path.dirname(HERE), 
 
 MAX_PARTS = 8
 MAX_LAYERS = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 NUM_LISTS = 12
 NUM_KERNELS = 15
 (IN_NODES, OUT_NODES, OWNED_OUT_NODES, SELF_IDS_IN, SELF_IDS_OUT, TO_IDS, FROM_IDS,
@@ -24,6 +24,7 @@ FLAG_SERIAL_ROUNDS = 1
 FLAG_KEEP_CANDIDATES = 2
 FLAG_TRANSPOSE = 4   # graph mode: also the slices by source (T_INDPTR / T_INDICES), every layer but the deepest
 FLAG_TRANSPOSE_ALL = 8   # ... the deepest too (with FLAG_TRANSPOSE)
+T_SORTED_MAX = 128       # lists of a slice by source up to this length are sorted; longer ones (hubs) are not
 LIST_KINDS = {
     "in_nodes": IN_NODES, "out_nodes": OUT_NODES, "owned_out_nodes": OWNED_OUT_NODES,
     "self_ids_in": SELF_IDS_IN, "self_ids_out": SELF_IDS_OUT, "to_ids": TO_IDS, "from_ids": FROM_IDS,
@@ -74,6 +75,7 @@ class LayerMeta(C.Structure):
         ("off", (C.c_uint32 * (MAX_PARTS + 1)) * NUM_LISTS),
         ("pair_off", ((C.c_uint32 * (MAX_PARTS + 1)) * MAX_PARTS) * 2),
         ("indptr_len", C.c_uint32 * MAX_PARTS),
+        ("t_max_len", C.c_uint32 * MAX_PARTS),
     ]
 
 
@@ -353,6 +355,7 @@ class Engine:
                     "self_ids_in": lists[(l, SELF_IDS_IN)][g], "self_ids_out": lists[(l, SELF_IDS_OUT)][g],
                     "owned_degree": lists[(l, OWNED_DEGREE)][g], "gpu_id": g,
                     "t_indptr": lists[(l, T_INDPTR)][g], "t_indices": lists[(l, T_INDICES)][g],
+                    "t_max_len": int(lm.t_max_len[g]),
                 }
                 fr, to = lists[(l, FROM_IDS)][g], lists[(l, TO_IDS)][g]
                 bp["from_ids"] = [fr[int(lm.pair_off[0][g][p]):int(lm.pair_off[0][g][p + 1])] for p in range(P)]

@@ -329,7 +329,8 @@ def sage_cat_bwd_t(t_indptr, t_indices, indptr, gcat, y, n_src, n_pad):
 class SageSlice(C.Structure):
     """csl_sage_slice (cslicer_aggr.h)"""
     _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("self_ids_in", C.c_void_p),
-                ("t_indptr", C.c_void_p), ("t_indices", C.c_void_p), ("n_out", C.c_int64), ("n_in", C.c_int64)]
+                ("t_indptr", C.c_void_p), ("t_indices", C.c_void_p), ("n_out", C.c_int64), ("n_in", C.c_int64),
+                ("t_max_len", C.c_int64)]
 
 
 class SageStep(object):
@@ -364,10 +365,11 @@ class SageStep(object):
         for k, s in enumerate(slices):
             c = self._sl[k]
             c.indptr, c.indices, c.self_ids_in = s.ptr(A.INDPTR), s.ptr(A.INDICES), s.ptr(A.SELF_IDS_IN)
-            if k and s.count(A.T_INDPTR) != s.n_in + 1:
+            # (an EMPTY layer -- a rank's empty share of a short minibatch -- has no row pointers at all)
+            if k and s.count(A.T_INDPTR) != s.n_in + 1 and (s.n_in or s.n_out or s.count(A.T_INDPTR)):
                 raise ValueError("layer %d has no slice by source: create the engine with flags=FLAG_TRANSPOSE" % k)
             c.t_indptr, c.t_indices = (s.ptr(A.T_INDPTR), s.ptr(A.T_INDICES)) if k else (None, None)
-            c.n_out, c.n_in = s.n_out, s.n_in
+            c.n_out, c.n_in, c.t_max_len = s.n_out, s.n_in, s.t_max_len
         L = _lib()
         need = L.csl_sage_fwd_bwd_workspace(self.L, self._dims, self._sl, self.row_pad, self.n_slabs)
         if need < 0:
@@ -660,7 +662,7 @@ class GatLayerLocal(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, attn_l, attn_r, bias, indptr, indices, self_ids_in, n_out, slope, elu, row_pad,
-                weight_grad, t_indptr=None, t_indices=None):
+                weight_grad, t_indptr=None, t_indices=None, t_max_len=0):
         H, D = attn_l.shape
         Cw = H * D
         n_in, mp = x.shape[0], x.shape[0]
@@ -697,7 +699,7 @@ class GatLayerLocal(torch.autograd.Function):
         # the slice by source (engine flags FLAG_TRANSPOSE | FLAG_TRANSPOSE_ALL): the backward then writes the gradient
         # of z row by row instead of scattering it with atomics into a zeroed buffer
         ctx.by_source = ((_i32(t_indptr), _i32(t_indices)) if t_indptr is not None and t_indptr.numel() == n_in + 1
-                         else None)
+                         and t_max_len <= _abi.T_SORTED_MAX else None)     # (a hub's list: the atomic form)
         return out
 
     @staticmethod
@@ -739,7 +741,7 @@ class GatLayerLocal(torch.autograd.Function):
              "csl_gat_logits_bwd_acc_f32")
         gw = weight_grad(g_z, xp)
         gx = (g_z @ weight)[:n_in] if ctx.needs_input_grad[0] else None
-        return gx, gw, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None
+        return gx, gw, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None, None
 
 
 def attention_gather(indptr, indices, u_in, v_in, n_rows):

@@ -58,7 +58,7 @@ class Slice(object):
     t_indptr / t_indices: the slice by source (engine flag FLAG_TRANSPOSE; empty otherwise and for the deepest layer).
     from_all / to_all: the per-peer lists back to back (receiver / sender order, the own one empty)."""
 
-    __slots__ = ("part", "n_parts", "n_in", "n_out", "n_owned", "n_edges", "from_counts", "to_counts",
+    __slots__ = ("part", "n_parts", "n_in", "n_out", "n_owned", "n_edges", "from_counts", "to_counts", "t_max_len",
                  "_t", "_origin", "_lbase", "_lm") + \
         tuple(_SLICE_LISTS) + ("from_ids", "to_ids")
 
@@ -137,6 +137,7 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
             # rows per peer of the boundary lists (from_ids[p] / to_ids[p]; the own entry is empty)
             s.from_counts = [int(lm.pair_off[0][g][p + 1]) - int(lm.pair_off[0][g][p]) for p in range(P)]
             s.to_counts = [int(lm.pair_off[1][g][p + 1]) - int(lm.pair_off[1][g][p]) for p in range(P)]
+            s.t_max_len = int(lm.t_max_len[g])      # longest list of the slice by source (hubs: > _abi.T_SORTED_MAX)
             row[g] = s
         out.append(row)
     return out
@@ -407,7 +408,8 @@ class DistSAGEModel(nn.Module):
         """A single part holding every node (one GPU): each layer is one `_SageLayerLocal` node.  `feat_table` is
         the resident [N, F] feature matrix; the deepest layer indexes it through its slice's in_nodes."""
         L = len(slices)
-        if all(slices[l][part].t_indptr.numel() for l in range(L - 1)) and L > 1:
+        if (L > 1 and all(slices[l][part].t_indptr.numel() and slices[l][part].t_max_len <= _abi.T_SORTED_MAX
+                          for l in range(L - 1))):
             # the engine emitted the slices by source: one node for the model, gathered input gradients
             args = []
             for k, conv in enumerate(self.convs):
@@ -487,7 +489,7 @@ class DistGATConv(nn.Module):
             g = parts[0]
             return {g: aggr.GatLayerLocal.apply(x[g], self.fc.weight, self.attn_l, self.attn_r, self.bias, sl[g].indptr,
                                                 sl[g].indices, sl[g].self_ids_in, sl[g].n_out, self.slope, bool(elu),
-                                                ROW_PAD, _weight_grad, sl[g].t_indptr, sl[g].t_indices)}
+                                                ROW_PAD, _weight_grad, sl[g].t_indptr, sl[g].t_indices, sl[g].t_max_len)}
         out = self._forward_parts(sl, x)
         return {g: torch.nn.functional.elu(v) for g, v in out.items()} if elu else out
 

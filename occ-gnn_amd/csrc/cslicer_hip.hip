@@ -1709,11 +1709,21 @@ __global__ __launch_bounds__(TN) void k_tsum(LArgs a, uint32_t* __restrict__ tsu
   if (!tslice(a, t, s, g) || blockIdx.x * TT >= t.n_in) return;
   __shared__ uint32_t s_w[NW];
   const uint32_t u0 = blockIdx.x * TT + threadIdx.x * 8;
-  uint32_t x = 0;
+  uint32_t x = 0, mx = 0;
 #pragma unroll
-  for (int k = 0; k < 8; k++) x += u0 + k < t.n_in ? t.cnt[u0 + k] : 0u;
+  for (int k = 0; k < 8; k++) {
+    const uint32_t c = u0 + k < t.n_in ? t.cnt[u0 + k] : 0u;
+    x += c;
+    mx = c > mx ? c : mx;
+  }
   const uint32_t tot = block_sum(x, s_w);
   if (threadIdx.x == 0) tsum[(size_t)blockIdx.y * ttiles + blockIdx.x] = tot;
+  // the slice's longest list (csl_layer_meta.t_max_len; the round's memset zeroed it)
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t y = __shfl_down(mx, o);
+    mx = y > mx ? y : mx;
+  }
+  if (lane_id() == 0 && mx) atomicMax(&a.meta[s].layer[a.layer].t_max_len[g], mx);
 }
 __global__ __launch_bounds__(TN) void k_tptr(LArgs a, const uint32_t* __restrict__ tsum, uint32_t ttiles) {
   TSlice t;
@@ -1788,7 +1798,11 @@ __global__ __launch_bounds__(TN) void k_tsort(LArgs a) {
     }
     return;
   }
-  // a hub (a source that thousands of the minibatch's rows sampled): heap sort, O(len log len) whatever the order
+  // a hub (a source that thousands of the minibatch's rows sampled) is left as it is: a single thread sorting 10^4
+  // entries in global memory took 10-25 ms of the round (profiles/hub_probe.py), and a consumer does not gather over
+  // such a list anyway (cslicer_hip.h, CSL_T_SORTED_MAX / t_max_len)
+  if (len > CSL_T_SORTED_MAX) return;
+  // heap sort, O(len log len) whatever the order
   auto sift = [&](int root, int end) {
     const int x = v[root];
     for (;;) {

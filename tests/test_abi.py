@@ -43,7 +43,7 @@ def test_abi_version_and_struct_layout():
     L = _abi.load()
     assert L.csl_abi_version() == _abi.ABI_VERSION
     # csl_layer_meta: 4 u32 + 10*(8+1) u32 offsets + 2*8*(8+1) pair offsets + 8 indptr lengths
-    assert C.sizeof(_abi.LayerMeta) == 4 * (4 + 12 * 9 + 2 * 8 * 9 + 8)
+    assert C.sizeof(_abi.LayerMeta) == 4 * (4 + 12 * 9 + 2 * 8 * 9 + 8 + 8)
     assert C.sizeof(_abi.SampleMeta) == 8 + 16 + 4 * C.sizeof(_abi.LayerMeta)
     assert L.csl_kernel_name(3).decode() == "k_sample"
     names = [L.csl_kernel_name(k).decode() for k in range(_abi.NUM_KERNELS)]

@@ -406,6 +406,40 @@ def test_native_step_matches_the_autograd_path(mods, B, row_pad):
     eng.close()
 
 
+def test_native_step_with_hub_nodes_falls_back_to_the_scatter_form(mods):
+    """A graph whose rows all point at three hubs: the hubs' lists in the slices by source are thousands of entries
+    long (t_max_len > CSL_T_SORTED_MAX), so the native step scatters that layer's input gradient with atomics instead
+    of letting one wave walk the list; same loss and gradients as the autograd path on the same slices."""
+    abi, aggr, sg = mods
+    torch.manual_seed(4)
+    n, deg, F0, hidden, classes, B = 20000, 10, 16, 32, 5, 512
+    rng = np.random.default_rng(4)
+    nb = rng.integers(0, n, size=(n, deg))
+    nb[:, :3] = np.array([5, 9, 17])
+    nb[[5, 9, 17]] = rng.integers(100, n, size=(3, deg))
+    indptr = np.arange(n + 1, dtype=np.int64) * deg
+    indices = np.sort(nb, axis=1).reshape(-1).astype(np.int64)
+    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(6, 5, 4), max_batch=B, mode=abi.MODE_GRAPH,
+                     flags=abi.FLAG_TRANSPOSE)
+    eng.submit_seeds([rng.permutation(n)[:B]])
+    slices = sg.slices_of(eng)
+    assert max(slices[l][0].t_max_len for l in range(2)) > abi.T_SORTED_MAX
+    feats = torch.randn(n, F0, device="cuda")
+    labels = torch.randint(0, classes, (n,), device="cuda")
+    model = sg.DistSAGEModel(F0, hidden, classes, n_layers=3).cuda()
+    out = model.forward_local(slices, feats)            # (falls back to one node per layer, atomic scatter)
+    assert type(out.grad_fn).__name__ != "_SageModelLocalBackward"
+    loss = aggr.SoftmaxCE.apply(out, slices[0][0].out_nodes, labels, 1.0 / B)
+    loss.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    step = aggr.SageStep(model, 256, 4)
+    got_loss = torch.zeros(1, device="cuda")
+    step([slices[2][0], slices[1][0], slices[0][0]], feats, labels, 1.0 / B, got_loss)
+    torch.testing.assert_close(got_loss[0], loss.detach(), rtol=1e-5, atol=1e-6)
+    assert float((step.grads - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    eng.close()
+
+
 @pytest.mark.parametrize("H,masked", [(256, True), (32, False), (100, True)])
 def test_sage_cat_bwd_by_source_matches_atomic_scatter(mods, H, masked):
     """csl_sage_cat_bwd_t_f32 over the engine's slice by source == csl_sage_cat_bwd_f32 (atomics) followed by
