@@ -651,6 +651,24 @@ class GatLogits(torch.autograd.Function):
         return g_z, buf[:H * D].view(H, D), buf[H * D:2 * H * D].view(H, D)
 
 
+class PaddedRows(object):
+    """The first `n` rows of `t` [mp, width]: mp = n rounded up so that GEMM shapes repeat, rows n.. are zero.  What the
+    fused GAT layers hand to each other, so that no layer copies its input into a padded buffer again."""
+    __slots__ = ("t", "n")
+
+    def __init__(self, t, n):
+        self.t, self.n = t, int(n)
+
+
+def padded_rows(n, width, row_pad, device):
+    """an uninitialised PaddedRows buffer whose padding rows are zeroed"""
+    mp = (n + row_pad - 1) // row_pad * row_pad if row_pad and n >= row_pad else n
+    t = torch.empty((mp, width), dtype=torch.float32, device=device)
+    if mp != n:
+        t[n:].zero_()
+    return PaddedRows(t, n)
+
+
 class GatLayerLocal(torch.autograd.Function):
     """A whole DistGATConv layer (+ ELU) of a single part (nothing to exchange) as ONE autograd node:
     z = x W^T (library GEMM on the row-padded input), attention logits (csl_gat_logits_fwd_f32), destination logits
@@ -662,16 +680,22 @@ class GatLayerLocal(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, attn_l, attn_r, bias, indptr, indices, self_ids_in, n_out, slope, elu, row_pad,
-                weight_grad, t_indptr=None, t_indices=None, t_max_len=0):
+                weight_grad, t_indptr=None, t_indices=None, t_max_len=0, n_rows=None, pad_out=False):
+        """n_rows: x is ALREADY the row-padded buffer of a PaddedRows (its first n_rows rows are the input); pad_out:
+        return the output as the padded buffer [pad(n_out), H*D] (zero rows behind n_out) for the next layer."""
         H, D = attn_l.shape
         Cw = H * D
         n_in, mp = x.shape[0], x.shape[0]
-        if row_pad and n_in >= row_pad:
+        if n_rows is not None:
+            n_in = int(n_rows)
+        elif row_pad and n_in >= row_pad:
             mp = (n_in + row_pad - 1) // row_pad * row_pad
         x = _f32(x)
-        if mp != n_in or not x.is_contiguous():
+        if n_rows is not None and x.is_contiguous():
+            xp = x
+        elif mp != n_in or not x.is_contiguous():
             xp = torch.empty((mp, x.shape[1]), dtype=torch.float32, device=x.device)
-            xp[:n_in].copy_(x)
+            xp[:n_in].copy_(x[:n_in])
             if mp != n_in:
                 xp[n_in:].zero_()
         else:
@@ -691,11 +715,13 @@ class GatLayerLocal(torch.autograd.Function):
         n = torch.empty((n_out, Cw), dtype=torch.float32, device=dev)
         _chk(L.csl_gat_fwd_f32(_p(indptr), _p(indices), n_out, _p(el), _p(er_out), _p(z), H, D, slope, _p(m), _p(s), _p(n),
                                _stream()), "csl_gat_fwd_f32")
-        out = torch.empty((n_out, Cw), dtype=torch.float32, device=dev)
+        out = padded_rows(n_out, Cw, row_pad, dev).t if pad_out else torch.empty((n_out, Cw), dtype=torch.float32,
+                                                                                  device=dev)
         _chk(L.csl_gat_finish_fwd_f32(_p(n), _p(s), _p(b), n_out, H, D, 1 if elu else 0, _p(out), _stream()),
              "csl_gat_finish_fwd_f32")
         ctx.save_for_backward(xp, weight, al, ar, z, el, er_out, m, s, n, out, indptr, indices, self_ids_in)
         ctx.cfg = (n_in, n_out, H, D, slope, bool(elu), weight_grad)
+        ctx.x_rows = x.shape[0]
         # the slice by source (engine flags FLAG_TRANSPOSE | FLAG_TRANSPOSE_ALL): the backward then writes the gradient
         # of z row by row instead of scattering it with atomics into a zeroed buffer
         ctx.by_source = ((_i32(t_indptr), _i32(t_indices)) if t_indptr is not None and t_indptr.numel() == n_in + 1
@@ -740,8 +766,12 @@ class GatLayerLocal(torch.autograd.Function):
                                           C.c_void_p(g_al.data_ptr()), C.c_void_p(g_ar.data_ptr()), scratch, _stream()),
              "csl_gat_logits_bwd_acc_f32")
         gw = weight_grad(g_z, xp)
-        gx = (g_z @ weight)[:n_in] if ctx.needs_input_grad[0] else None
-        return gx, gw, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None, None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = g_z @ weight                        # rows behind n_in are zero (g_z's are)
+            if gx.shape[0] != ctx.x_rows:
+                gx = gx[:ctx.x_rows]
+        return gx, gw, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def attention_gather(indptr, indices, u_in, v_in, n_rows):

@@ -480,17 +480,24 @@ class DistGATConv(nn.Module):
         el, er = aggr.GatLogits.apply(z, self.attn_l, self.attn_r)
         return z, el, er
 
-    def forward_parts(self, sl, x, elu=False):
+    def forward_parts(self, sl, x, elu=False, pad_out=False):
         """sl[g]: Slice of part g, x[g]: features of sl[g].in_nodes.  Returns per part the [n_owned, H*D]
-        output rows of the nodes it owns (frontier order); elu: apply the ELU that follows a hidden layer."""
+        output rows of the nodes it owns (frontier order); elu: apply the ELU that follows a hidden layer; pad_out
+        (fused single-part layer only): hand the output on as an aggr.PaddedRows."""
         parts = sorted(sl.keys())
-        if len(parts) == 1 and sl[parts[0]].n_parts == 1 and x[parts[0]].is_cuda and not _NO_LOCAL_FUSE:
-            # one part holding every node: the whole layer (+ ELU) as one autograd node
+        if len(parts) == 1 and sl[parts[0]].n_parts == 1 and not _NO_LOCAL_FUSE and (
+                isinstance(x[parts[0]], aggr.PaddedRows) or x[parts[0]].is_cuda):
+            # one part holding every node: the whole layer (+ ELU) as one autograd node.  The layers hand each other
+            # row-padded buffers (aggr.PaddedRows), so that none copies its input into a padded GEMM operand again
             g = parts[0]
-            return {g: aggr.GatLayerLocal.apply(x[g], self.fc.weight, self.attn_l, self.attn_r, self.bias, sl[g].indptr,
-                                                sl[g].indices, sl[g].self_ids_in, sl[g].n_out, self.slope, bool(elu),
-                                                ROW_PAD, _weight_grad, sl[g].t_indptr, sl[g].t_indices, sl[g].t_max_len)}
-        out = self._forward_parts(sl, x)
+            xin = x[g]
+            padded = isinstance(xin, aggr.PaddedRows)
+            out = aggr.GatLayerLocal.apply(xin.t if padded else xin, self.fc.weight, self.attn_l, self.attn_r, self.bias,
+                                           sl[g].indptr, sl[g].indices, sl[g].self_ids_in, sl[g].n_out, self.slope,
+                                           bool(elu), ROW_PAD, _weight_grad, sl[g].t_indptr, sl[g].t_indices,
+                                           sl[g].t_max_len, xin.n if padded else None, bool(pad_out))
+            return {g: aggr.PaddedRows(out, sl[g].n_out) if pad_out else out}
+        out = self._forward_parts(sl, {g: (v.t[:v.n] if isinstance(v, aggr.PaddedRows) else v) for g, v in x.items()})
         return {g: torch.nn.functional.elu(v) for g, v in out.items()} if elu else out
 
     def _forward_parts(self, sl, x):
@@ -589,9 +596,12 @@ class DistGATModel(nn.Module):
         L = len(slices)
         parts = sorted(slices[0].keys())
         x = {g: feats[g] for g in parts}
+        fused = (len(parts) == 1 and slices[0][parts[0]].n_parts == 1 and not _NO_LOCAL_FUSE and
+                 (isinstance(x[parts[0]], aggr.PaddedRows) or x[parts[0]].is_cuda))
         for k, conv in enumerate(self.convs):
-            x = conv.forward_parts(slices[L - 1 - k], x, elu=k + 1 < len(self.convs))
-            if k + 1 == len(self.convs):
+            last = k + 1 == len(self.convs)
+            x = conv.forward_parts(slices[L - 1 - k], x, elu=not last, pad_out=fused and not last)
+            if last:
                 x = {g: x[g].view(-1, self.heads, conv.D).mean(1)[:, :self.n_classes] for g in parts}
         return x
 

@@ -181,7 +181,12 @@ class Trainer(object):
             # gather of owned input features (row v // P of the owner v % P), int32 indices, float4 row kernel
             _roctx.push("gather")
             rows = deep.in_nodes if self.P == 1 else self.local_row[deep.in_nodes.long()]
-            x = aggr.gather_rows(self.feat, rows)
+            if self.kind == "gat" and not self.rank_path and self.P == 1 and not splitgnn._NO_LOCAL_FUSE:
+                # straight into the row-padded buffer the fused GAT layer multiplies (no second copy of 0.3 GB)
+                x = aggr.padded_rows(rows.numel(), self.feat.shape[1], splitgnn.ROW_PAD, self.dev)
+                aggr.gather_rows(self.feat, rows, out=x.t[:x.n])
+            else:
+                x = aggr.gather_rows(self.feat, rows)
             _roctx.pop()
             t1 = time.perf_counter()
             _roctx.push("forward")
