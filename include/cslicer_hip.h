@@ -77,8 +77,9 @@ enum {
   CSL_INDPTR = 7,           /* graph mode: CSR row pointers over out_nodes, len(out_nodes)+1 per part */
   CSL_INDICES = 8,          /* graph mode: local index into in_nodes of every edge's source */
   CSL_OWNED_DEGREE = 9,     /* graph mode: edges of each owned out node over ALL parts (mean divisor) */
-  /* graph mode + CSL_FLAG_TRANSPOSE, every layer but the deepest (with CSL_FLAG_TRANSPOSE_ALL: every layer): the slice by SOURCE, for the backward pass of the
-   * aggregation as a gather (each source-gradient row written once: no atomics, nothing to pre-zero).
+  /* graph mode + CSL_FLAG_TRANSPOSE, every layer but the deepest (with CSL_FLAG_TRANSPOSE_ALL: every layer): the slice
+   * by SOURCE, for the backward pass of the aggregation as a gather (each source-gradient row written once: no atomics,
+   * nothing to pre-zero).
    * For in node u of slice g, entries [t_indptr[u], t_indptr[u+1]) of t_indices hold, ascending: ~r (negative) when u
    * is the self source of owned out node r (self_ids_in/self_ids_out), then the out row r of every edge u -> r of the
    * slice's CSR (a row twice when the edge was sampled twice).  Lists longer than CSL_T_SORTED_MAX entries -- hub nodes
