@@ -204,12 +204,24 @@ def compat_leg(indptr, indices, args, B, samples=384, workers=32):
             "in_nodes_of_last_sample": ids, "constructor_seconds": t_load}
 
 
+def pmc_counter_sum(csv_path, counter, kernel):
+    """(sum of the counter's values in rocprofv3's unit -- KiB for FETCH_SIZE / WRITE_SIZE --, launches) of `kernel` (name
+    without namespace, return type and argument list) in a rocprofv3 counter_collection.csv"""
+    import csv
+    total, n = 0.0, 0
+    for r in csv.DictReader(open(csv_path)):
+        nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        if nm == kernel and r["Counter_Name"] == counter:
+            total += float(r["Counter_Value"])
+            n += 1
+    return total, n
+
+
 def live_pmc_traffic(args, kernel, rounds=8, warm=2, timeout=240):
     """HBM-side traffic of `kernel`, bytes per launch, measured NOW: two child runs of this same workload under rocprofv3,
     one per counter (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, each with --kernel-trace only: MI355X_MICROARCH.md's recipe),
     rounds on one HIP stream.  FETCH_SIZE counts 64-B units of read requests that are all 128 B on this path
     (profiles/pmc_rdsize.sh), hence 2 x FETCH_SIZE + WRITE_SIZE.  Returns (bytes per launch, launches) or raises."""
-    import csv
     import glob
     import shutil
     import subprocess
@@ -235,12 +247,7 @@ def live_pmc_traffic(args, kernel, rounds=8, warm=2, timeout=240):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 raise RuntimeError("rocprofv3 wrote no counter file for " + counter)
-            kib, n = 0.0, 0
-            for r in csv.DictReader(open(files[0])):
-                nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-                if nm == kernel and r["Counter_Name"] == counter:
-                    kib += float(r["Counter_Value"])
-                    n += 1
+            kib, n = pmc_counter_sum(files[0], counter, kernel)
             if n == 0:
                 raise RuntimeError("no launch of %s in the %s pass" % (kernel, counter))
             tot[counter] = (kib, n)

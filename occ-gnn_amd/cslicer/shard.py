@@ -58,6 +58,17 @@ def round_plan(n_batches, streams, first_batch, n_steps):
     return plan
 
 
+def dp_chunk(batch_index, global_batch, n_nodes, rank, world):
+    """Data-parallel dealing of ONE minibatch: positions [lo, hi) of the node order that rank `rank` of `world` trains
+    of minibatch `batch_index` (contiguous chunks of ceil(global_batch / world); the last minibatch of the order may
+    be short, a chunk may be empty), and the minibatch's total seed count (the loss divisor on every rank)."""
+    lo = batch_index * global_batch
+    hi = min(lo + global_batch, n_nodes)
+    chunk = (global_batch + world - 1) // world
+    a = min(lo + rank * chunk, hi)
+    return a, min(a + chunk, hi), max(hi - lo, 0)
+
+
 def max_over_ranks(seconds, dist=None, device=None):
     """The job's wall time is the slowest rank's (bench.py contract)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -332,11 +332,9 @@ class DataParallelTrainer(Trainer):
     def _submit(self, first, n, slot):
         mine = []
         for j in range(n):
-            lo = (first + j) * self.global_B
-            hi = min(lo + self.global_B, len(self.nodes))
-            a = min(lo + self.dp_rank * self.chunk, hi)
-            mine.append(self.nodes[a:min(a + self.chunk, hi)])
-            self._den[(j, slot)] = max(hi - lo, 1)
+            a, b, total = shard.dp_chunk(first + j, self.global_B, len(self.nodes), self.dp_rank, self.dp_world)
+            mine.append(self.nodes[a:b])
+            self._den[(j, slot)] = max(total, 1)
         self.eng.submit_seeds(mine, slot=slot)
 
     def _loss_den(self, stream, slot, n_seeds):

@@ -91,3 +91,26 @@ def test_split_k_linear_on_cpu():
         assert torch.allclose(a_, b_, rtol=1e-12, atol=1e-12)
     (gx, gw) = torch.autograd.grad(splitgnn._SplitKLinear.apply(x, w, None), (x, w), gy)
     assert torch.allclose(gw, g0[1], rtol=1e-12, atol=1e-12)
+
+
+def test_pmc_counter_sum_reads_a_rocprofv3_counter_file(tmp_path):
+    """bench.pmc_counter_sum: per-kernel sum and launch count from rocprofv3's counter_collection.csv (what
+    roofline.traffic is computed from in the run)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = tmp_path / "1_counter_collection.csv"
+    f.write_text(
+        "Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,"
+        "Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,"
+        "Start_Timestamp,End_Timestamp\n"
+        '1,1,4,1,9,9,1024,7,"(anonymous namespace)::k_sample((anonymous namespace)::LArgs)",256,0,0,48,0,80,FETCH_SIZE,1000.5,1,2\n'
+        '2,2,4,1,9,9,1024,7,"(anonymous namespace)::k_sample((anonymous namespace)::LArgs)",256,0,0,48,0,80,FETCH_SIZE,2000,3,4\n'
+        '3,3,4,1,9,9,1024,8,"void (anonymous namespace)::k_bucket<false>((anonymous namespace)::LArgs)",512,0,0,46,0,80,FETCH_SIZE,50,5,6\n'
+        '4,4,4,1,9,9,1024,7,"(anonymous namespace)::k_sample((anonymous namespace)::LArgs)",256,0,0,48,0,80,WRITE_SIZE,7,7,8\n')
+    assert bench.pmc_counter_sum(str(f), "FETCH_SIZE", "k_sample") == (3000.5, 2)
+    assert bench.pmc_counter_sum(str(f), "FETCH_SIZE", "k_bucket<false>") == (50.0, 1)
+    assert bench.pmc_counter_sum(str(f), "WRITE_SIZE", "k_emit") == (0.0, 0)

@@ -93,3 +93,23 @@ def test_round_plan_covers_every_minibatch_once():
     part = shard.round_plan(10, 4, 7, 9)          # 7 8 9 | 0 1 2 3 | 4 5
     assert part == [(7, 3), (0, 4), (4, 2)]
     assert shard.round_plan(0, 4, 0, 5) == [] and shard.round_plan(5, 4, 0, 0) == []
+
+
+def test_data_parallel_chunks_cover_every_minibatch_once():
+    """shard.dp_chunk: the ranks' chunks of a minibatch are disjoint, in order, and together the whole minibatch --
+    also for the short last minibatch of the node order, where trailing ranks get an empty chunk."""
+    from cslicer import shard
+    for n_nodes, B, W in [(1000, 250, 3), (1000, 256, 4), (1024, 1024, 8), (10, 4, 3), (7, 7, 1), (100, 33, 5)]:
+        n_batches = (n_nodes + B - 1) // B
+        seen = []
+        for b in range(n_batches):
+            total_expected = min(B, n_nodes - b * B)
+            at = b * B
+            for r in range(W):
+                lo, hi, total = shard.dp_chunk(b, B, n_nodes, r, W)
+                assert total == total_expected
+                assert lo == at and hi >= lo and hi - lo <= (B + W - 1) // W
+                seen.extend(range(lo, hi))
+                at = hi
+            assert at == b * B + total_expected
+        assert seen == list(range(n_nodes))
