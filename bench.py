@@ -352,6 +352,9 @@ def finish(out, rank, dist):
         # first-class: the end-to-end half of the headline metric (strong scaling on several GPUs)
         out["e2e_iters_per_sec"] = out["e2e"]["iters_per_sec"]
         out["e2e_scaling"] = "strong" if out.get("n_gpus", 1) > 1 else None
+        dp = out["e2e"].get("data_parallel") or {}
+        if "iters_per_sec" in dp:     # several GPUs: the same step data-parallel (cslicer.train.DataParallelTrainer)
+            out["e2e_data_parallel_iters_per_sec"] = dp["iters_per_sec"]
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
