@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--serial-rounds", action="store_true",
                     help="no overlap of consecutive rounds (profiling: undisturbed per-kernel durations)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
-    ap.add_argument("--e2e-steps", type=int, default=128,
+    ap.add_argument("--e2e-steps", type=int, default=256,
                     help="end-to-end training minibatches for the secondary iters/s figure (0 = skip)")
     ap.add_argument("--no-e2e-multi", action="store_true", help="several GPUs: skip the split-parallel training leg")
     ap.add_argument("--no-live-pmc", action="store_true",
@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--e2e-hidden", type=int, default=256)
     ap.add_argument("--e2e-feat", type=int, default=100)
     ap.add_argument("--e2e-classes", type=int, default=47)
-    ap.add_argument("--e2e-streams", type=int, default=32, help="minibatches the trainer's engine slices per round")
+    ap.add_argument("--e2e-streams", type=int, default=64, help="minibatches the trainer's engine slices per round")
     ap.add_argument("--no-tuned-gemms", action="store_true",
                     help="e2e leg: hipBLASLt's default heuristic instead of the recorded TunableOp selections")
     ap.add_argument("--no-compat", action="store_true", help="skip the reference-surface (host lists) leg")
