@@ -117,6 +117,7 @@ class Trainer(object):
             self._loss_ring, self._ring_at = torch.zeros((4096,), dtype=torch.float32, device=self.dev), 0
         self.t_forward = self.t_slice = 0.0
         self.steps_done = 0
+        self._round_base, self._slot_done, self._ahead = 0, [None] * self.SLOTS, None
         # units of the steps done (measurement only): per model layer k the output rows, source rows and edges
         self.units = [{"rows": 0, "src": 0, "edges": 0} for _ in range(self.L)]
 
@@ -228,11 +229,15 @@ class Trainer(object):
         self.steps_done += 1
         return loss.detach()
 
-    def run(self, n_steps, first_batch=0):
+    def run(self, n_steps, first_batch=0, then=None):
         """n_steps minibatches starting at minibatch `first_batch` of the node order (wrapping around the epoch),
         up to S per engine round; the next round is sliced while this one trains.  A round never crosses the end
         of the epoch: the last round of an epoch holds the remaining n_batches % S minibatches, the last of them
-        possibly short -- every minibatch of the epoch is trained exactly once."""
+        possibly short -- every minibatch of the epoch is trained exactly once.
+
+        then = (first_batch, n_steps) of the run() call that will follow: its first round is sliced while this call's
+        last round trains, so the follow-up call starts without waiting for the slicer (the caller MUST make that call
+        next: the round is already submitted and has advanced the streams' mt19937 positions)."""
         losses = []
         plan = shard.round_plan(self.n_batches, self.S, first_batch, n_steps)
         if not plan:
@@ -242,23 +247,35 @@ class Trainer(object):
             if self._loss_ring.numel() < n_steps:
                 self._loss_ring = torch.zeros((n_steps,), dtype=torch.float32, device=self.dev)
             self._ring_at = 0
-        done = [None] * self.SLOTS     # per slot: event behind the last step that read the slot
+        base = self._round_base        # rounds keep rotating through the result slots from call to call
+        done = self._slot_done         # per slot: event behind the last step that read the slot
 
-        def submit(r):
-            ev = done[r % self.SLOTS]
+        def submit(r, entry):
+            slot = (base + r) % self.SLOTS
+            ev = done[slot]
             if ev is not None:
                 ev.synchronize()                          # the slot's previous consumer has finished
-            self._submit(plan[r][0], plan[r][1], r % self.SLOTS)
+            self._submit(entry[0], entry[1], slot)
 
-        submit(0)
+        ahead, self._ahead = self._ahead, None
+        if ahead is not None and ahead != plan[0]:
+            raise RuntimeError("run(then=...) announced the round %r, this call starts with %r" % (ahead, plan[0]))
+        if ahead is None:
+            submit(0, plan[0])
+        nxt = shard.round_plan(self.n_batches, self.S, then[0], then[1])[:1] if then else []
         for r in range(len(plan)):
             if r + 1 < len(plan):
-                submit(r + 1)
+                submit(r + 1, plan[r + 1])
+            elif nxt:
+                submit(r + 1, nxt[0])
+                self._ahead = nxt[0]
+            slot = (base + r) % self.SLOTS
             for s in range(plan[r][1]):
-                losses.append(self._step(s, r % self.SLOTS))
+                losses.append(self._step(s, slot))
             ev = torch.cuda.Event()
             ev.record()
-            done[r % self.SLOTS] = ev
+            done[slot] = ev
+        self._round_base = (base + len(plan)) % self.SLOTS
         torch.cuda.synchronize()
         return [float(x) for x in losses]
 
