@@ -34,6 +34,8 @@ struct LtApi {
   decltype(&hipblasLtMatrixLayoutCreate) LayoutCreate = nullptr;
   decltype(&hipblasLtMatrixLayoutSetAttribute) LayoutSet = nullptr;
   decltype(&hipblasLtMatmulDescCreate) DescCreate = nullptr;
+  decltype(&hipblasLtMatmulDescDestroy) DescDestroy = nullptr;
+  decltype(&hipblasLtMatrixLayoutDestroy) LayoutDestroy = nullptr;
   decltype(&hipblasLtMatmulDescSetAttribute) DescSet = nullptr;
   decltype(&hipblasLtMatmulPreferenceCreate) PrefCreate = nullptr;
   decltype(&hipblasLtMatmulPreferenceSetAttribute) PrefSet = nullptr;
@@ -112,6 +114,8 @@ bool load_api() {
   const bool ok = bind(lib, "hipblasLtCreate", a.Create) && bind(lib, "hipblasLtMatrixLayoutCreate", a.LayoutCreate) &&
                   bind(lib, "hipblasLtMatrixLayoutSetAttribute", a.LayoutSet) &&
                   bind(lib, "hipblasLtMatmulDescCreate", a.DescCreate) &&
+                  bind(lib, "hipblasLtMatmulDescDestroy", a.DescDestroy) &&
+                  bind(lib, "hipblasLtMatrixLayoutDestroy", a.LayoutDestroy) &&
                   bind(lib, "hipblasLtMatmulDescSetAttribute", a.DescSet) &&
                   bind(lib, "hipblasLtMatmulPreferenceCreate", a.PrefCreate) &&
                   bind(lib, "hipblasLtMatmulPreferenceSetAttribute", a.PrefSet) &&
@@ -162,8 +166,22 @@ int run(const Plan& p, const float* A, const float* B, float* C, const float* bi
 }
 
 // *ran: the GEMM itself has been issued (with the algorithm the plan keeps) as part of making the plan
+int make_plan_impl(const Key& key, Plan& p, const float* A, const float* B, float* C, const float* bias, hipStream_t st,
+                   bool* ran);
 int make_plan(const Key& key, Plan& p, const float* A, const float* B, float* C, const float* bias, hipStream_t st,
               bool* ran) {
+  const int r = make_plan_impl(key, p, A, B, C, bias, st, ran);
+  if (r) {  // a plan that could not be made leaves nothing behind
+    if (p.la) g.api.LayoutDestroy(p.la);
+    if (p.lb) g.api.LayoutDestroy(p.lb);
+    if (p.lc) g.api.LayoutDestroy(p.lc);
+    if (p.desc) g.api.DescDestroy(p.desc);
+    p = Plan();
+  }
+  return r;
+}
+int make_plan_impl(const Key& key, Plan& p, const float* A, const float* B, float* C, const float* bias, hipStream_t st,
+                   bool* ran) {
   *ran = false;
   int transa, transb, batch, epi;
   long long m, n, k, lda, ldb, ldc, sa, sb, sc;
