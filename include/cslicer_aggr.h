@@ -217,6 +217,23 @@ int csl_gemm_load_plans(const char* path);
  * gradient computed as n_slabs independent row slabs (a batched csl_gemm_f32 with transa) */
 int csl_sum_slabs_f32(const float* slabs, int64_t n, int32_t n_slabs, float* out, void* stream);
 
+/* ---- a GraphSAGE layer's forward as ONE kernel on the fp32 matrix cores (csrc/sage_mfma.hip) ----
+ * DistSageConv.forward (python/layers/dist_sageconv.py:66-80: self_gather, gather / mean over the slice CSR of
+ * python/data/bipartite.py:61-67, concat, Linear(2*in, out)) without the gathered operand ever being read back from HBM:
+ *   y[r, 0:out) = act_out( [ act_in(x[map(self_ids[r])]) | mean_{e in CSR row r} act_in(x[map(indices[e])]) ] . W^T + bias )
+ * for r < n (a zero self block for self_ids[r] = -1, a zero mean for an empty row); rows [n, n_pad) get act_out(bias), what
+ * the two-kernel form (csl_sage_cat_f32's zero rows + csl_gemm_f32) leaves there.  map(i) = rowmap ? rowmap[i] : i;
+ * act_* = ReLU when relu_* != 0.  W [out, ldw >= 2 H] row-major (torch's Linear.weight), bias [out] or NULL.
+ * cat != NULL: the operand [n_pad, ldc >= 2 H] is also written (the backward's weight-gradient GEMM reads it).
+ * v_mfma_f32_32x32x2_f32: exact fp32, a k-ordered fmaf chain per output.  H % 4 == 0, out <= 256, ldx / ldw / ldc
+ * multiples of 4, x / W / cat / wpack 16-byte aligned.  wpack: csl_sage_fwd_mfma_scratch(H, out) floats (W re-packed
+ * in MFMA operand order, rewritten by every call). */
+int64_t csl_sage_fwd_mfma_scratch(int32_t H, int32_t out);
+int csl_sage_fwd_mfma_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
+                          const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, int64_t n,
+                          int64_t n_pad, int32_t H, int32_t out, int32_t relu_in, int32_t relu_out, float* cat,
+                          int64_t ldc, float* y, int64_t ldy, float* wpack, void* stream);
+
 /* ---- one training step of the GraphSAGE model on ONE part (python/train.py:56-88 on a GPU that holds every node) ----
  * Forward, cross-entropy and backward for one minibatch as one call: the fused kernels above + csl_gemm_f32, issued
  * from native code (a step is ~25 launches and 8 GEMMs of 5-90 us: issued one by one from an interpreter they cost more

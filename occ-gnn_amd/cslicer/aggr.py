@@ -22,7 +22,7 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_sum_slabs_f32", "csl_sage_fwd_bwd_f32", "csl_sage_fwd_bwd_workspace", "csl_sage_last_error",
            "csl_gemm_save_plans", "csl_gemm_load_plans", "csl_softmax_ce_partial_f32", "csl_reduce_multi_f32",
            "csl_sage_rank_fwd_bwd_f32", "csl_sage_rank_workspace", "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch",
-           "csl_gat_bwd_t_f32"]
+           "csl_gat_bwd_t_f32", "csl_sage_fwd_mfma_f32", "csl_sage_fwd_mfma_scratch"]
 _ready = False
 
 
@@ -77,6 +77,10 @@ def _lib():
         L.csl_gat_finish_bwd_scratch.argtypes = [i64, i32, i32]
         L.csl_gat_finish_bwd_scratch.restype = i64
         L.csl_gemm_load_plans.argtypes = [C.c_char_p]
+        L.csl_sage_fwd_mfma_scratch.argtypes = [i32, i32]
+        L.csl_sage_fwd_mfma_scratch.restype = i64
+        L.csl_sage_fwd_mfma_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, vp, i64,
+                                            vp, i64, vp, vp]
         _ready = True
     return L
 
@@ -227,6 +231,30 @@ def sage_cat(x, self_ids, n, n_pad, indptr=None, indices=None, owned=None, deg=N
     _chk(_lib().csl_sage_cat_f32(*args, n, n_pad, _p(cat), cat.stride(0), H, 1 if relu_in else 0, _stream()),
          "csl_sage_cat_f32")
     return cat
+
+
+def sage_fwd_mfma(x, self_ids, indptr, indices, weight, bias, n, n_pad, rowmap=None, relu_in=False, relu_out=False,
+                  want_cat=False):
+    """A GraphSAGE layer's forward as one kernel on the fp32 matrix cores (csl_sage_fwd_mfma_f32):
+    y [n_pad, out] = act([x[map(self_ids)] | mean over the CSR row of x[map(indices)]] weight^T + bias); with want_cat
+    also the operand [n_pad, 2 H] (what sage_cat returns).  weight [out, 2 H] (torch's Linear.weight)."""
+    x, weight = _f32(x), _f32(weight)
+    H, out = x.shape[1], weight.shape[0]
+    L = _lib()
+    nw = L.csl_sage_fwd_mfma_scratch(H, out)
+    if nw < 0:
+        raise ValueError("csl_sage_fwd_mfma_f32: unsupported widths (in %% 4 == 0, out <= 256): in %d, out %d" % (H, out))
+    wpack = torch.empty((nw,), dtype=torch.float32, device=x.device)
+    y = torch.empty((n_pad, out), dtype=torch.float32, device=x.device)
+    cat = torch.empty((n_pad, 2 * H), dtype=torch.float32, device=x.device) if want_cat else None
+    nul = C.c_void_p(0)
+    _chk(L.csl_sage_fwd_mfma_f32(_p(_i32(indptr)), _p(_i32(indices)), _p(_i32(self_ids)),
+                                 _p(rowmap) if rowmap is not None else nul, _p(x), x.stride(0), _p(weight),
+                                 weight.stride(0), _p(_f32(bias)) if bias is not None else nul, n, n_pad, H, out,
+                                 1 if relu_in else 0, 1 if relu_out else 0, _p(cat) if want_cat else nul,
+                                 cat.stride(0) if want_cat else 0, _p(y), y.stride(0), _p(wpack), _stream()),
+         "csl_sage_fwd_mfma_f32")
+    return (y, cat) if want_cat else y
 
 
 def sage_cat_bwd(indptr, indices, self_ids, gcat, n, n_src):
