@@ -74,34 +74,20 @@ def main():
         return
     if int(os.environ.get("CSLICER_MFMA_DBG", "0")) & 64:
         for _ in range(3):
-            y = fused(False)
+            fused(True)
         torch.cuda.synchronize()
-        y = fused(False).cpu()
-        bm = 64 if H <= 104 and not int(os.environ["CSLICER_MFMA_DBG"]) & 8 else 32
-        w = torch.stack([y[k::bm, :8] for k in range(4)], 1).contiguous().view(torch.int32).numpy().astype(np.int64) & 0xFFFFFFFF
-        # [tile, wave, (start, gathered, loop0, loop1, end, hw_id, xcc)]
-        t0 = w[..., 0].min()
-        hw, xcc = w[..., 5], w[..., 6] & 0xF
-        cu = (xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xF)
-        simd = (hw >> 4) & 3
-        print("tiles %d; distinct CUs %d; kernel span %.1f us" % (w.shape[0], len(np.unique(cu)), (w[..., 4].max() - t0) / 100))
-        ph = [("start->gathered", 0, 1), ("barrier wait", 1, 2), ("multiply loop", 2, 3), ("epilogue", 3, 4)]
-        for name, i, j in ph:
-            d = (w[..., j] - w[..., i]) / 100.0
-            print("  %-16s median %6.2f us  mean %6.2f  max %6.2f" % (name, np.median(d), d.mean(), d.max()))
-        # per CU: tiles, busy span, sum of loop time per SIMD
-        cus = np.unique(cu)
-        ntile = np.array([(cu[:, 0] == c).sum() for c in cus])
-        print("  tiles per CU: min %d  median %d  max %d" % (ntile.min(), np.median(ntile), ntile.max()))
-        c0 = cus[np.argmax(ntile)]
-        sel = np.flatnonzero(cu[:, 0] == c0)
-        print("  timeline of the busiest CU (tile: start gathered loop0 loop1 end, us since kernel start; simd of wave 0..3)")
-        for tix in sel[np.argsort(w[sel, 0, 0])]:
-            print("   tile %5d: %s  simd %s" % (tix, " ".join("%7.2f" % ((w[tix, 0, k] - t0) / 100) for k in range(5)), simd[tix].tolist()))
-        starts = np.sort((w[:, 0, 0] - t0) / 100.0)
-        print("  block start times (us): first 5 %s ... 256th %.2f  768th %.2f  769th %.2f  last %.2f" % (
-            np.round(starts[:5], 2).tolist(), starts[min(255, len(starts) - 1)], starts[min(767, len(starts) - 1)],
-            starts[min(768, len(starts) - 1)], starts[-1]))
+        _, cat = fused(True)
+        w = cat.flatten()[:256 * 64 * 2 * 4].view(torch.int32).cpu().numpy().astype(np.int64).reshape(256, 64, 2, 4) & 0xFFFFFFFF
+        S = int(w[0, 0, 0, 3])
+        nst = S + 5
+        t0 = w[:, 0, :, 0].min()
+        print("steps per workgroup %d (tiles %d); kernel span %.1f us" % (nst, S, (w[:, :nst, :, 2].max() - t0) / 100))
+        for role, name in ((0, "consumer"), (1, "producer")):
+            work = (w[:, :nst, role, 1] - w[:, :nst, role, 0]) / 100.0
+            wait = (w[:, :nst, role, 2] - w[:, :nst, role, 1]) / 100.0
+            print("  %s: work per step (us, median over workgroups): %s" % (name, " ".join("%.2f" % x for x in np.median(work, 0))))
+            print("  %s: barrier wait per step:                      %s" % (name, " ".join("%.2f" % x for x in np.median(wait, 0))))
+        print("  workgroup 0 step ends (us): %s" % " ".join("%.1f" % ((x - t0) / 100) for x in w[0, :nst, 0, 2]))
         return
     y2 = two()
     y1 = fused(False)
