@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--serial-rounds", action="store_true",
                     help="no overlap of consecutive rounds (profiling: undisturbed per-kernel durations)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
-    ap.add_argument("--e2e-steps", type=int, default=256,
+    ap.add_argument("--e2e-steps", type=int, default=2048,
                     help="end-to-end training minibatches for the secondary iters/s figure (0 = skip)")
     ap.add_argument("--no-e2e-multi", action="store_true", help="several GPUs: skip the split-parallel training leg")
     ap.add_argument("--no-live-pmc", action="store_true",
@@ -573,13 +573,16 @@ def main():
                      model=args.e2e_model, heads=args.e2e_heads, feat_dim=args.e2e_feat,
                      overlap=bool(args.e2e_overlap and world > 1 and args.e2e_model == "sage"))
         tr.set_nodes(perm)
-        # warm-up (allocator, rng window, GEMM plans); the timed call's first round is sliced during its last round
+        # warm-up (allocator, rng window, GEMM plans).  Steady state: every call slices one round ahead -- the warm-up
+        # slices the timed call's first round, the timed call slices the first round of a (never trained) successor -- so
+        # the timed region slices exactly as many rounds as it trains
+        after = (48 + args.e2e_steps) % tr.n_batches
         tr.run(48, then=(48, args.e2e_steps))
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tr.reset_units()
-        tr.run(args.e2e_steps, first_batch=48)
+        tr.run(args.e2e_steps, first_batch=48, then=(after, args.e2e_streams))
         torch.cuda.synchronize()
         barrier()
         t_e2e = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)
@@ -611,7 +614,8 @@ def main():
             "iters_per_sec": args.e2e_steps / t_e2e, "ms_per_iter": 1e3 * t_e2e / args.e2e_steps,
             "steps": args.e2e_steps,
             "config": "split-parallel %s fanout %s, batch %d (global), %d part(s) = %d GPU(s), features %d, "
-                      "hidden %d, classes %d, fp32, Adam; slice+gather+fwd+bwd+step" % (
+                      "hidden %d, classes %d, fp32, Adam; slice+gather+fwd+bwd+step; every call slices one round ahead, so the timed "
+                      "region slices as many rounds as it trains" % (
                           "GraphSAGE" if args.e2e_model == "sage" else "GAT (%d heads)" % args.e2e_heads,
                           "/".join(map(str, fan)), B, world, world, args.e2e_feat, args.e2e_hidden, args.e2e_classes),
             "scaling": "strong",
@@ -627,11 +631,12 @@ def main():
                                  fanouts=fan, streams=args.e2e_streams, hidden=args.e2e_hidden, device=device,
                                  feat_dim=args.e2e_feat)
         tr.set_nodes(perm)
+        after = (48 + args.e2e_steps) % tr.n_batches
         tr.run(48, then=(48, args.e2e_steps))
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        tr.run(args.e2e_steps, first_batch=48)
+        tr.run(args.e2e_steps, first_batch=48, then=(after, args.e2e_streams))   # (slices as many rounds as it trains)
         torch.cuda.synchronize()
         barrier()
         t_dp = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)

@@ -7,25 +7,31 @@
 // deepest layer of the products step (82 k rows x [100 | 100] x 256) the two-kernel form moved 65 MB of operand out to HBM
 // and back in (csl_sage_cat_f32 58 us + library GEMM 96 us).
 //
-// Structure: ONE persistent workgroup per CU, 12 waves with fixed roles.
-//   * 8 producer waves gather tile after tile of 32 output rows into an LDS ring of two operand tiles (and, optionally,
+// Structure: ONE persistent workgroup per CU, 8 waves with fixed roles, two per SIMD, 256 registers each.
+//   * 4 producer waves gather tile after tile of 32 output rows into an LDS ring of two operand tiles (and, optionally,
 //     write the operand out: the backward's weight-gradient GEMM reads it).  The gather of a tile is the end of a chain
 //     of four dependent loads (CSR row pointers -> indices -> feature-table row map -> feature rows); the chain is
 //     software-pipelined over FOUR tiles, so every step issues all four stages' loads together and waits once.
-//   * 4 consumer waves (one per SIMD) multiply the previous tile by the whole of W with v_mfma_f32_32x32x2_f32 (exact
-//     fp32: a k-ordered fmaf chain per output), add the bias, apply the ReLU and leave the 32 x out result in a second LDS
-//     ring; the producers store it as whole rows in the next step.  A consumer therefore has no store in its vector-memory
-//     queue: its only global traffic is the B operand, prefetched two steps of k ahead.
-//   One workgroup barrier per step.  (A first version -- every workgroup gathers its tile, then multiplies it, three
-//   workgroups per CU -- ran all workgroups in lockstep: 150 us, the gather and multiply phases never overlapped and
-//   the accumulator stores of a whole chip at once took 12-25 us per tile: profiles/r3_mfma/.)
+//   * 4 consumer waves (one per SIMD) multiply the previous tile by W with v_mfma_f32_32x32x2_f32 (exact fp32: a
+//     k-ordered fmaf chain per output, started from the bias), apply the ReLU and leave the 32 x out result in a second
+//     LDS ring; the producers store it as whole rows in the next step.  A wave owns 64 output columns, and its slice of W
+//     is STATIONARY ON THE CU: 8 registers per lane per k-group of 8 for the first KS groups (19 of the 25 at in = 100:
+//     152 registers next to 32 of accumulators), the next KL groups in LDS (6: 48 KB), and only what is beyond that
+//     (layers wider than in = 100) streamed from L2 two groups ahead.  At in = 100 a consumer touches no global memory
+//     at all in the steady state.
+//   One workgroup barrier per step.
+// What came before (profiles/r3_mfma/): (v1) every workgroup gathers its tile, then multiplies it, three workgroups per
+// CU: all workgroups ran in lockstep, 150 us, the gather and multiply phases never overlapped and the accumulator stores
+// of a whole chip at once took 12-25 us per tile.  (v2) these roles with B streamed from L2 by the consumers: 142 us, a
+// consumer's B loads sat in the CU's memory pipeline behind the producers' HBM gathers (12.3 us per 32-row tile with the
+// gather running, 9.2 without, 6.9 with no loads in the loop at all).
 //
 // Operands.  A (the gathered rows) comes from LDS, row-major with a leading dimension of 4*odd floats so that the
-// 16-lane groups of a ds_read_b128 down a column of rows touch 64 different banks.  B comes straight from L2 into
-// registers, one 16-byte load per lane per n-tile per 8 k: W is re-packed once per call (k_pack_w) so that this load is
-// contiguous per wave.  The MFMA sums over k in any order as long as A and B agree, so one float4 of a lane feeds FOUR
-// consecutive MFMAs: lanes 0-31 (k index 0 of the instruction) hold k = 8q .. 8q+3 of their row / column, lanes 32-63
-// (k index 1) hold k = 8q+4 .. 8q+7, and MFMA j of the group uses element j of both.
+// 16-lane groups of a ds_read_b128 down a column of rows touch 64 different banks.  W is re-packed once per call
+// (k_pack_w) so that a lane's B values of a k-group are one contiguous 16-byte load.  The MFMA sums over k in any order
+// as long as A and B agree, so one float4 of a lane feeds FOUR consecutive MFMAs: lanes 0-31 (k index 0 of the
+// instruction) hold k = 8q .. 8q+3 of their row / column, lanes 32-63 (k index 1) hold k = 8q+4 .. 8q+7, and MFMA j of
+// the group uses element j of both.
 //
 // All of it is plain HIP; the C ABI is in cslicer_aggr.h.
 #include <hip/hip_runtime.h>
@@ -42,13 +48,15 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NCONS = 4;                    // consumer (MFMA) waves: one per SIMD
-constexpr int NPROD = 8;                    // producer (gather / store) waves
-constexpr int TBP = 64 * (NCONS + NPROD);   // 768 threads
+constexpr int NPROD = 4;                    // producer (gather / store) waves: one per SIMD
+constexpr int TBP = 64 * (NCONS + NPROD);   // 512 threads: two waves per SIMD, 256 registers each
 constexpr int PT = 64 * NPROD;              // producer threads
 constexpr int BM = 32;                      // rows of a tile: one MFMA m-tile
 constexpr int EC = 6;                       // edges of a row whose feature rows are requested together
-constexpr int EMAX = 16;                    // resolved neighbour rows staged per output row (longer rows: slow path)
+constexpr int NR = 4;                       // rows a group of 32 producer lanes gathers at once (BM / (PT / 32))
+constexpr int EMAX = 16;                    // resolved neighbour rows staged per output row (longer rows: generic path)
 constexpr int IDXW = EMAX + 2;              // [degree, self row, neighbour rows]
+constexpr int NSL = EMAX * BM / PT;         // edge slots of a row per producer thread in the index pipeline (2)
 
 struct FwdArgs {
   const int* indptr;
@@ -58,26 +66,30 @@ struct FwdArgs {
   const float* x;
   long long ldx;
   const float4* wp;   // packed W: [K2/8][NTp][64 lanes] float4
+  const float* zero;  // 128 zero floats behind it: what a lane with nothing to fetch loads
   const float* bias;
   float* cat;         // optional [n_pad][ldc]
   long long ldc;
   float* y;           // [n_pad][ldy]
   long long ldy;
   long long n, n_pad;
-  int H, out, NTp, relu_in, relu_out, lda, ldo, n_tiles, vec_y;
+  int H, out, NTp, relu_in, relu_out, lda, n_tiles;
   // the index pipeline loads unconditionally (at element 0 where a lane has nothing to fetch): never-null stand-ins
   const int* indptr_ld;
   const int* indices_ld;
   const int* self_ld;
   const int* rowmap_ld;
-  int dbg;            // diagnostics (CSLICER_MFMA_DBG): 1 = no feature loads, 2 = no multiply
+  int dbg;            // diagnostics (CSLICER_MFMA_DBG): 1 = no feature loads, 2 = no multiply, 64 = step stamps into cat
 };
 
 // W [out][ldw] -> wp[q][nt][lane].j = W[32 nt + (lane & 31)][8 q + 4 (lane >> 5) + j]   (zero beyond `out`)
 __global__ __launch_bounds__(256) void k_pack_w(const float* __restrict__ W, long long ldw, int out, int KQ, int NTp,
                                                 float4* __restrict__ wp) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)KQ * NTp * 64) return;
+  if (i >= (long long)KQ * NTp * 64) {
+    if (i < (long long)KQ * NTp * 64 + 32) wp[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero row behind the packed W
+    return;
+  }
   const int lane = (int)(i & 63);
   const long long t = i >> 6;
   const int nt = (int)(t % NTp), q = (int)(t / NTp);
@@ -93,176 +105,187 @@ __device__ __forceinline__ float4 relu4(float4 v, float lo) {
 }
 __device__ __forceinline__ void acc4(float4& a, const float4 b) { a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w; }
 
-// ---- producer: one step.  Tile ids of this workgroup: b, b + G, b + 2 G, ... (S of them); step t gathers tile t's
-// feature rows (stage F), resolves tile t+1's rows through the row map (R), reads tile t+2's indices (I) and tile
-// t+3's row pointers (P), and stores the result tile t-2 the consumers left in LDS.
+// ---- producers.  Tile ids of this workgroup: b, b + G, b + 2 G, ... (S of them).  Step t finishes tile t's feature
+// rows (stage F), resolves tile t+2's rows through the row map (R), reads tile t+3's indices (I) and tile t+4's row
+// pointers (P), and stores the result tile t-2 the consumers left in LDS.
 struct ProdState {
-  int p_e0, p_deg, p_sid;    // stage P -> I: CSR range and self id of this thread's row
-  int i_raw, i_sid, i_deg;   // stage I -> R: this thread's edge slot (raw index), self id, degree
+  int p_e0, p_deg, p_sid;         // stage P -> I: CSR range and self id of this thread's row
+  int i_raw[NSL], i_sid, i_deg;   // stage I -> R: this thread's edge slots (raw indices), self id, degree
+  float4 r[2][2 * (EC + 1)];      // stage F in flight (fast path): two chunks of [two rows x (self + EC edges)] quads
 };
 
-__device__ __forceinline__ void producer_step(const FwdArgs& a, int t, int S, int b, int G, int j, float* Abuf,
-                                              float* Obuf, int* Ibuf, ProdState& st) {
-  const int H = a.H, lda = a.lda, ldo = a.ldo;
-  const float lo = a.relu_in ? 0.f : -__builtin_inff();
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // ---- the result tile t-2: LDS -> y, whole rows
-  if (t >= 2 && t - 2 < S) {
-    const float* O = Obuf + ((t - 2) & 1) * BM * ldo;
-    const long long row0 = (long long)(b + (long long)(t - 2) * G) * BM;
-    const int q4 = ldo >> 2;   // float4 per staged row
-    for (int e = j; e < BM * q4; e += PT) {
-      const int rl = e / q4, c = (e - rl * q4) * 4;
-      const long long r = row0 + rl;
-      if (r >= a.n_pad || c >= a.out) continue;
-      const float4 v = *reinterpret_cast<const float4*>(O + rl * ldo + c);
-      float* yp = a.y + r * a.ldy + c;
-      if (a.vec_y) {
-        *reinterpret_cast<float4*>(yp) = v;
-      } else {
-        yp[0] = v.x;
-        if (c + 1 < a.out) yp[1] = v.y;
-        if (c + 2 < a.out) yp[2] = v.z;
-        if (c + 3 < a.out) yp[3] = v.w;
-      }
-    }
+// the index pipeline: thread j is row pr of the tile, edge slots ps and ps + 8.  Its loads are issued unconditionally,
+// at element 0 where the lane (or the whole step) has nothing to fetch, and the values are selected later (pipe_finish):
+// a branch around a load ends the compiler's scheduling region.
+struct PipeLoads {
+  int m_nbr[NSL], m_self, m_raw[NSL], m_e0, m_e1, m_sid;
+  bool okP;
+};
+__device__ __forceinline__ void pipe_issue(const FwdArgs& a, int t, int S, int b, int G, int j, const ProdState& st,
+                                           PipeLoads& pl) {
+  const int pr = j >> 3, ps = j & 7;
+#pragma unroll
+  for (int k = 0; k < NSL; k++) pl.m_nbr[k] = a.rowmap_ld[(a.rowmap && st.i_raw[k] >= 0) ? st.i_raw[k] : 0];
+  pl.m_self = a.rowmap_ld[(a.rowmap && st.i_sid >= 0) ? st.i_sid : 0];
+#pragma unroll
+  for (int k = 0; k < NSL; k++)
+    pl.m_raw[k] = a.indices_ld[(a.indices && ps + 8 * k < st.p_deg) ? (long long)st.p_e0 + ps + 8 * k : 0];
+  const long long rP = (long long)(b + (long long)(t + 4) * G) * BM + pr;
+  pl.okP = t + 4 < S && rP < a.n;   // (t + 4 >= 0 always)
+  const long long rc = pl.okP ? rP : 0;
+  pl.m_e0 = a.indptr_ld[rc], pl.m_e1 = a.indptr_ld[rc + 1], pl.m_sid = a.self_ld[rc];
+}
+__device__ __forceinline__ void pipe_finish(const FwdArgs& a, int t, int S, int j, int* Ibuf, ProdState& st,
+                                            const PipeLoads& pl) {
+  const int pr = j >> 3, ps = j & 7;
+  if (t + 2 >= 0 && t + 2 < S) {
+    int* Iw = Ibuf + ((t + 6) % 3) * BM * IDXW + pr * IDXW;   // tile t+2's (tile T lives in slot (T + 4) % 3)
+#pragma unroll
+    for (int k = 0; k < NSL; k++) Iw[2 + ps + 8 * k] = st.i_raw[k] >= 0 ? (a.rowmap ? pl.m_nbr[k] : st.i_raw[k]) : -1;
+    if (ps == 0) Iw[0] = st.i_deg, Iw[1] = st.i_sid >= 0 ? (a.rowmap ? pl.m_self : st.i_sid) : -1;
   }
-
-  // ---- stage F: feature rows of tile t.  32 lanes per row, this group's rows g and g + 16, both in flight.
-  const bool doF = t >= 0 && t < S;
-  const int g = j >> 5, gl = j & 31;
-  const int* I0 = Ibuf + (t & 1) * BM * IDXW + g * IDXW;
-  const int* I1 = I0 + 16 * IDXW;
-  int deg0 = 0, deg1 = 0, sr0 = -1, sr1 = -1;
-  int s0[EC], s1[EC];
-  float4 v0[EC], v1[EC], sv0 = z4, sv1 = z4;
-  int c = gl * 4;
 #pragma unroll
-  for (int u = 0; u < EC; u++) s0[u] = -1, s1[u] = -1, v0[u] = z4, v1[u] = z4;
-  if (doF) {
-    deg0 = I0[0], sr0 = I0[1], deg1 = I1[0], sr1 = I1[1];
-#pragma unroll
-    for (int u = 0; u < EC; u++) {
-      s0[u] = u < deg0 ? I0[2 + u] : -1;
-      s1[u] = u < deg1 ? I1[2 + u] : -1;
-    }
-    if (c < H && !(a.dbg & 1)) {
-      if (sr0 >= 0) sv0 = *reinterpret_cast<const float4*>(a.x + (long long)sr0 * a.ldx + c);
-      if (sr1 >= 0) sv1 = *reinterpret_cast<const float4*>(a.x + (long long)sr1 * a.ldx + c);
-#pragma unroll
-      for (int u = 0; u < EC; u++) {
-        if (s0[u] >= 0) v0[u] = *reinterpret_cast<const float4*>(a.x + (long long)s0[u] * a.ldx + c);
-        if (s1[u] >= 0) v1[u] = *reinterpret_cast<const float4*>(a.x + (long long)s1[u] * a.ldx + c);
-      }
-    }
-  }
-
-  // ---- the index pipeline: thread j is (row pr, edge slot ps) of the tile
-  const int pr = j >> 4, ps = j & 15;
-  // Every load below is issued unconditionally, at element 0 where the lane (or the whole step) has nothing to fetch,
-  // and its value is selected after stage F has been finished: a branch around a load, divergent or uniform, ends the
-  // compiler's scheduling region and it then waits for the whole queue before the next stage's loads are issued.
-  // stage R: tile t+1's raw indices -> feature-table rows
-  const bool doR = t + 1 >= 0 && t + 1 < S;
-  const int m_nbr = a.rowmap_ld[(a.rowmap && st.i_raw >= 0) ? st.i_raw : 0];
-  const int m_self = a.rowmap_ld[(a.rowmap && st.i_sid >= 0) ? st.i_sid : 0];
-  // stage I: tile t+2's indices
-  const int m_raw = a.indices_ld[(a.indices && ps < st.p_deg) ? (long long)st.p_e0 + ps : 0];
-  // stage P: tile t+3's row pointers and self ids
-  const long long rP = (long long)(b + (long long)(t + 3) * G) * BM + pr;
-  const bool okP = t + 3 < S && rP < a.n;   // (t + 3 >= 0 always)
-  const long long rc = okP ? rP : 0;
-  const int m_e0 = a.indptr_ld[rc], m_e1 = a.indptr_ld[rc + 1], m_sid = a.self_ld[rc];
-
-  // ---- finish stage F (its loads are the oldest in the queue)
-  if (doF) {
-    const long long row0 = (long long)(b + (long long)t * G) * BM;
-    float* A = Abuf + (t & 1) * BM * lda;
-    const float inv0 = 1.0f / (float)(deg0 > 1 ? deg0 : 1), inv1 = 1.0f / (float)(deg1 > 1 ? deg1 : 1);
-    for (; c < H; c += 128) {
-      if (c != gl * 4 && !(a.dbg & 1)) {   // rows wider than 128 columns: further quads of the same rows
-        sv0 = z4, sv1 = z4;
-        if (sr0 >= 0) sv0 = *reinterpret_cast<const float4*>(a.x + (long long)sr0 * a.ldx + c);
-        if (sr1 >= 0) sv1 = *reinterpret_cast<const float4*>(a.x + (long long)sr1 * a.ldx + c);
-#pragma unroll
-        for (int u = 0; u < EC; u++) {
-          v0[u] = z4, v1[u] = z4;
-          if (s0[u] >= 0) v0[u] = *reinterpret_cast<const float4*>(a.x + (long long)s0[u] * a.ldx + c);
-          if (s1[u] >= 0) v1[u] = *reinterpret_cast<const float4*>(a.x + (long long)s1[u] * a.ldx + c);
-        }
-      }
-      if (sr0 >= 0) sv0 = relu4(sv0, lo);
-      if (sr1 >= 0) sv1 = relu4(sv1, lo);
-      float4 m0 = z4, m1 = z4;
-#pragma unroll
-      for (int u = 0; u < EC; u++) {
-        if (s0[u] >= 0) acc4(m0, relu4(v0[u], lo));
-        if (s1[u] >= 0) acc4(m1, relu4(v1[u], lo));
-      }
-      // rows with more than EC edges (shallower layers' fanouts): staged rows up to EMAX, then through the index arrays
-      if (!(a.dbg & 1)) {
-        for (int u = EC; u < deg0; u++) {
-          long long s;
-          if (u < EMAX) {
-            s = I0[2 + u];
-          } else {
-            s = a.indices[(long long)a.indptr[row0 + g] + u];
-            if (a.rowmap) s = a.rowmap[s];
-          }
-          acc4(m0, relu4(*reinterpret_cast<const float4*>(a.x + s * a.ldx + c), lo));
-        }
-        for (int u = EC; u < deg1; u++) {
-          long long s;
-          if (u < EMAX) {
-            s = I1[2 + u];
-          } else {
-            s = a.indices[(long long)a.indptr[row0 + g + 16] + u];
-            if (a.rowmap) s = a.rowmap[s];
-          }
-          acc4(m1, relu4(*reinterpret_cast<const float4*>(a.x + s * a.ldx + c), lo));
-        }
-      }
-      m0.x *= inv0, m0.y *= inv0, m0.z *= inv0, m0.w *= inv0;
-      m1.x *= inv1, m1.y *= inv1, m1.z *= inv1, m1.w *= inv1;
-      *reinterpret_cast<float4*>(A + g * lda + c) = sv0;
-      *reinterpret_cast<float4*>(A + g * lda + H + c) = m0;
-      *reinterpret_cast<float4*>(A + (g + 16) * lda + c) = sv1;
-      *reinterpret_cast<float4*>(A + (g + 16) * lda + H + c) = m1;
-      if (a.cat && !(a.dbg & 64)) {
-        if (row0 + g < a.n_pad) {
-          float* o = a.cat + (row0 + g) * a.ldc;
-          *reinterpret_cast<float4*>(o + c) = sv0;
-          *reinterpret_cast<float4*>(o + H + c) = m0;
-        }
-        if (row0 + g + 16 < a.n_pad) {
-          float* o = a.cat + (row0 + g + 16) * a.ldc;
-          *reinterpret_cast<float4*>(o + c) = sv1;
-          *reinterpret_cast<float4*>(o + H + c) = m1;
-        }
-      }
-    }
-  }
-
-  // ---- hand the pipeline on
-  if (doR) {
-    int* In = Ibuf + ((t + 1) & 1) * BM * IDXW + pr * IDXW;
-    In[2 + ps] = st.i_raw >= 0 ? (a.rowmap ? m_nbr : st.i_raw) : -1;
-    if (ps == 0) In[0] = st.i_deg, In[1] = st.i_sid >= 0 ? (a.rowmap ? m_self : st.i_sid) : -1;
-  }
-  st.i_raw = (a.indices && ps < st.p_deg) ? m_raw : -1, st.i_sid = st.p_sid, st.i_deg = st.p_deg;
-  st.p_e0 = okP ? m_e0 : 0, st.p_deg = okP ? m_e1 - m_e0 : 0, st.p_sid = okP ? m_sid : -1;
+  for (int k = 0; k < NSL; k++) st.i_raw[k] = (a.indices && ps + 8 * k < st.p_deg) ? pl.m_raw[k] : -1;
+  st.i_sid = st.p_sid, st.i_deg = st.p_deg;
+  st.p_e0 = pl.okP ? pl.m_e0 : 0, st.p_deg = pl.okP ? pl.m_e1 - pl.m_e0 : 0, st.p_sid = pl.okP ? pl.m_sid : -1;
 }
 
-// ---- consumer: multiply tile t-1 (LDS) by this wave's two n-tiles of W, leave act(. + bias) in the result ring.
-// B of k-group q sits in buffer q % 3 and is requested two groups ahead, A of group q in buffer q % 2, one ahead: the
-// loop is unrolled by six so that every buffer index is a constant (a rotation by register moves made the compiler
-// wait for each load right behind its issue).  Groups 0 and 1 of B never change: they stay in registers (rb).
-struct ConsRegs {
-  float4 rb[2][2];   // B of k-groups 0 and 1, n-tiles 0 and 1 of this wave
-  float bv0, bv1;    // bias of this lane's two columns
-};
+// ---- the fast path: rows of at most EP * EC edges, at most 128 columns.  A tile is 2 EP chunks of loads -- chunk
+// (P, p): rows g + 16 P and g + 16 P + 8 of this group, their self rows (p = 0) and edges [EC p, EC p + EC) -- over two
+// register sets; as soon as a chunk has been consumed its set takes the loads of the chunk after the next, of this tile
+// or of the next one, so two chunks of loads are in flight at every moment, barriers included.  No loop with a memory
+// operation in it between the issue and the use of a load: the compiler then waits with counted vmcnt instead of
+// draining the queue.
+template <int EP>
+__device__ __forceinline__ void chunk_issue(const FwdArgs& a, const int* I_tile, int g, int cl, int k, float4 (&r)[2 * (EC + 1)]) {
+  // every load is issued: a lane with nothing to fetch (no self row, a shorter row, a column beyond the width) reads a
+  // row of zeros.  No branch around a load (a join the compiler's wait insertion does not count across), and no select
+  // afterwards: on this chip the fp32 MFMA and the vector ALU share the fp32 lanes, so every vector instruction of a
+  // producer is taken from the consumer on the same SIMD.
+  const int P = k / EP, p = k % EP;
+#pragma unroll
+  for (int w = 0; w < 2; w++) {
+    const int* I = I_tile + (g + 16 * P + 8 * w) * IDXW;
+    const int deg = I[0], sr = I[1];
+    float4* rr = r + w * (EC + 1);
+    if (p == 0) {
+      const float* src = (sr >= 0 && cl >= 0) ? a.x + (long long)sr * a.ldx + cl : a.zero;
+      rr[0] = *reinterpret_cast<const float4*>(src);
+    }
+#pragma unroll
+    for (int e = 0; e < EC; e++) {
+      const float* src = (EC * p + e < deg && cl >= 0) ? a.x + (long long)I[2 + EC * p + e] * a.ldx + cl : a.zero;
+      rr[1 + e] = *reinterpret_cast<const float4*>(src);
+    }
+  }
+}
 
+template <int EP, bool RELU>
+__device__ __forceinline__ void producer_step_fast(const FwdArgs& a, int t, int S, int b, int G, int j, float* Abuf,
+                                                   int* Ibuf, ProdState& st) {
+  const int H = a.H, lda = a.lda;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  PipeLoads pl;
+  pipe_issue(a, t, S, b, G, j, st, pl);
+  const bool doF = t >= 0 && t < S, doN = t + 1 >= 0 && t + 1 < S;
+  const int g = j >> 5, gl = j & 31, c = gl * 4;
+  const int cl = c < H ? c : -1;                        // (lanes beyond the row's width fetch zeros)
+  const int* Ib = Ibuf + ((t + 4) % 3) * BM * IDXW;    // tile t's staged rows (initial values before tile 0's are there)
+  const int* In = doN ? Ibuf + ((t + 5) % 3) * BM * IDXW : Ib;    // tile t+1's (the last step loads the last tile again)
+  float* A = Abuf + (t & 1) * BM * lda;
+  float4 m[2];
+  m[0] = m[1] = z4;
+#pragma unroll
+  for (int k = 0; k < 2 * EP; k++) {
+    const int P = k / EP, p = k % EP;
+    float4(&r)[2 * (EC + 1)] = st.r[k % 2];
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      const int rl = g + 16 * P + 8 * w;
+      const float4* rr = r + w * (EC + 1);
+      if (p == 0) {
+        m[w] = z4;
+        const float4 s4 = RELU ? relu4(rr[0], 0.f) : rr[0];
+        if (doF && c < H) *reinterpret_cast<float4*>(A + rl * lda + c) = s4;
+      }
+#pragma unroll
+      for (int e = 0; e < EC; e++) acc4(m[w], RELU ? relu4(rr[1 + e], 0.f) : rr[1 + e]);
+      if (p == EP - 1) {
+        const int deg = Ib[rl * IDXW];
+        const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+        float4 mm = m[w];
+        mm.x *= inv, mm.y *= inv, mm.z *= inv, mm.w *= inv;
+        if (doF && c < H) *reinterpret_cast<float4*>(A + rl * lda + H + c) = mm;
+      }
+    }
+    // the set takes the chunk after the next: of this tile, or of the next one
+    if (k + 2 < 2 * EP) chunk_issue<EP>(a, Ib, g, cl, k + 2, r);
+    else chunk_issue<EP>(a, In, g, cl, k + 2 - 2 * EP, r);
+  }
+  pipe_finish(a, t, S, j, Ibuf, st, pl);
+}
+
+// ---- the generic path (rows of any length, any width): stage F of tile t is issued and waited for inside step t
+__device__ __forceinline__ void producer_step_slow(const FwdArgs& a, int t, int S, int b, int G, int j, float* Abuf,
+                                                   int* Ibuf, ProdState& st) {
+  const int H = a.H, lda = a.lda;
+  const float lo = a.relu_in ? 0.f : -__builtin_inff();
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  PipeLoads pl;
+  pipe_issue(a, t, S, b, G, j, st, pl);
+  if (t >= 0 && t < S) {
+    const int g = j >> 5, gl = j & 31;
+    const int* Ib = Ibuf + ((t + 4) % 3) * BM * IDXW;
+    const long long row0 = (long long)(b + (long long)t * G) * BM;
+    float* A = Abuf + (t & 1) * BM * lda;
+    for (int c = gl * 4; c < H; c += 128) {
+#pragma unroll
+      for (int u = 0; u < NR; u++) {
+        const int rl = g + 8 * u;
+        const int* I = Ib + rl * IDXW;
+        const int deg = I[0], sr = I[1];
+        float4 s4 = z4, m = z4;
+        if (!(a.dbg & 1)) {
+          if (sr >= 0) s4 = relu4(*reinterpret_cast<const float4*>(a.x + (long long)sr * a.ldx + c), lo);
+          for (int e = 0; e < deg; e++) {
+            long long s;
+            if (e < EMAX) {
+              s = I[2 + e];
+            } else {
+              s = a.indices[(long long)a.indptr[row0 + rl] + e];
+              if (a.rowmap) s = a.rowmap[s];
+            }
+            acc4(m, relu4(*reinterpret_cast<const float4*>(a.x + s * a.ldx + c), lo));
+          }
+        }
+        const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
+        m.x *= inv, m.y *= inv, m.z *= inv, m.w *= inv;
+        *reinterpret_cast<float4*>(A + rl * lda + c) = s4;
+        *reinterpret_cast<float4*>(A + rl * lda + H + c) = m;
+      }
+    }
+  }
+  pipe_finish(a, t, S, j, Ibuf, st, pl);
+}
+
+template <int MODE, bool RELU>   // 1, 2, 3: fast path with that many edge passes; 0: generic
+__device__ __forceinline__ void producer_loop(const FwdArgs& a, int S, int b, int G, int j, float* Abuf, int* Ibuf,
+                                              ProdState& st) {
+  // (no global store anywhere in a producer, diagnostics included: with stores and loads both pending in the queue the
+  // compiler stops counting and waits with vmcnt(0), which would drain the next tile's loads at every use of this one's)
+  for (int t = -4; t <= S + 1; t++) {
+    if (MODE == 0) producer_step_slow(a, t, S, b, G, j, Abuf, Ibuf, st);
+    else producer_step_fast<(MODE > 0 ? MODE : 1), RELU>(a, t, S, b, G, j, Abuf, Ibuf, st);
+    __syncthreads();
+  }
+}
+
+// ---- consumer: multiply tile t-1 (LDS) by this wave's two n-tiles of W and store act(. + bias).
+// k-groups [0, KS) of B are in registers (ws), groups [KS, KS + KL) in LDS (Wl: what the register file cannot hold next to
+// the accumulators; read one group ahead like A), groups beyond are streamed from L2: group q in buffer (q - KS - KL) % 3,
+// requested two groups ahead (the first two before the stationary part starts), the loop unrolled by six so that every
+// buffer index is a constant (a rotation by register moves made the compiler wait for each load right behind its issue).
+// A of group q sits in buffer q % 2, read one group ahead.
 #define MFMA8(AV, B0, B1)                                                   \
   acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, (B0).x, acc0, 0, 0, 0); \
   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).x, (B1).x, acc1, 0, 0, 0); \
@@ -273,108 +296,197 @@ struct ConsRegs {
   acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, (B0).w, acc0, 0, 0, 0); \
   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32((AV).w, (B1).w, acc1, 0, 0, 0);
 
-__device__ __forceinline__ void consumer_step(const FwdArgs& a, int t, int wave, int lane, const float* Abuf, float* Obuf,
-                                              const ConsRegs& cr) {
+template <int KS, int KL, bool STREAM>
+__device__ __forceinline__ void consumer_step(const FwdArgs& a, int t, int tile, int wave, int lane, const float* Abuf,
+                                              const float4* Wl, const float4 (&ws)[KS > 0 ? KS : 1][2], float bv0, float bv1) {
+  constexpr int K0 = KS + KL;   // first streamed group
   const int nt0 = 2 * wave;
-  const int lda = a.lda, ldo = a.ldo;
+  const int lda = a.lda;
   const float* A = Abuf + ((t - 1) & 1) * BM * lda;
-  float* O = Obuf + ((t - 1) & 1) * BM * ldo;
   const int KQ = (2 * a.H) / 8;
   const int h = lane >> 5, l31 = lane & 31;
   f32x16 acc0, acc1;
 #pragma unroll
-  for (int i = 0; i < 16; i++) acc0[i] = cr.bv0, acc1[i] = cr.bv1;   // C starts as the bias of the lane's column
+  for (int i = 0; i < 16; i++) acc0[i] = bv0, acc1[i] = bv1;   // C starts as the bias of the lane's column
   const float* ab = A + l31 * lda + 4 * h;
-  const float4* wb = a.wp + (long long)nt0 * 64 + lane;
-  const long long wstep = (long long)a.NTp * 64;
-  float4 bb[3][2], aa[2];
-  bb[0][0] = cr.rb[0][0], bb[0][1] = cr.rb[0][1], bb[1][0] = cr.rb[1][0], bb[1][1] = cr.rb[1][1];
-  bb[2][0] = bb[0][0], bb[2][1] = bb[0][1];
+  float4 aa[2];
   aa[0] = *reinterpret_cast<const float4*>(ab);
   aa[1] = aa[0];
-  int q0 = 0;
-  for (; q0 + 6 <= KQ; q0 += 6) {   // (loads past the last group re-read it: no branch, no drained queue)
+  constexpr int NB = STREAM ? 3 : 1;
+  float4 bb[NB][2];
+  const float4* wb = a.wp + (long long)nt0 * 64 + lane;
+  const long long wstep = (long long)a.NTp * 64;
+  if (STREAM) {
+    const int q1 = K0 < KQ ? K0 : KQ - 1, q2 = K0 + 1 < KQ ? K0 + 1 : KQ - 1;
+    bb[0][0] = wb[q1 * wstep], bb[0][1] = wb[q1 * wstep + 64];
+    bb[1 % NB][0] = wb[q2 * wstep], bb[1 % NB][1] = wb[q2 * wstep + 64];
+  }
+  // groups in registers
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const int q = q0 + i, qb = q + 2 < KQ ? q + 2 : KQ - 1, qa = q + 1 < KQ ? q + 1 : KQ - 1;
-      if (!(a.dbg & 256)) {
-        bb[(i + 2) % 3][0] = wb[qb * wstep];
-        bb[(i + 2) % 3][1] = wb[qb * wstep + 64];
+  for (int q = 0; q < ((a.dbg & 16) ? 0 : KS); q++) {
+    const int qa = q + 1 < KQ ? q + 1 : KQ - 1;
+    aa[(q + 1) % 2] = *reinterpret_cast<const float4*>(ab + 8 * qa);
+    MFMA8(aa[q % 2], ws[q][0], ws[q][1])
+  }
+  // groups in LDS: Wl[k][wave][n-tile][lane].  A real loop (two groups per trip): unrolled, the compiler hoists every
+  // LDS read to the top and spills
+  if (KL > 0) {
+    const float4* wl = Wl + wave * 128 + lane;
+    float4 lb[2][2];
+    lb[0][0] = wl[0], lb[0][1] = wl[64];
+#pragma unroll 1
+    for (int k0 = 0; k0 < KL; k0 += 2) {
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int k = k0 + i;
+        if (k < KL) {
+          const int q = KS + k, qa = q + 1 < KQ ? q + 1 : KQ - 1, kn = k + 1 < KL ? k + 1 : KL - 1;
+          lb[(i + 1) % 2][0] = wl[kn * (NCONS * 128)], lb[(i + 1) % 2][1] = wl[kn * (NCONS * 128) + 64];
+          aa[(KS + i + 1) % 2] = *reinterpret_cast<const float4*>(ab + 8 * qa);
+          MFMA8(aa[(KS + i) % 2], lb[i % 2][0], lb[i % 2][1])
+        }
       }
-      if (!(a.dbg & 512)) aa[(i + 1) % 2] = *reinterpret_cast<const float4*>(ab + 8 * qa);
-      MFMA8(aa[i % 2], bb[i % 3][0], bb[i % 3][1])
     }
   }
+  if (STREAM) {
+    int q0 = K0;
+    for (; q0 + 6 <= KQ; q0 += 6) {   // (loads past the last group re-read it: no branch, no drained queue)
 #pragma unroll
-  for (int i = 0; i < 5; i++) {   // the last KQ % 6 groups
-    const int q = q0 + i;
-    if (q < KQ) {
-      const int qb = q + 2 < KQ ? q + 2 : KQ - 1, qa = q + 1 < KQ ? q + 1 : KQ - 1;
-      bb[(i + 2) % 3][0] = wb[qb * wstep];
-      bb[(i + 2) % 3][1] = wb[qb * wstep + 64];
-      aa[(i + 1) % 2] = *reinterpret_cast<const float4*>(ab + 8 * qa);
-      MFMA8(aa[i % 2], bb[i % 3][0], bb[i % 3][1])
+      for (int i = 0; i < 6; i++) {
+        const int q = q0 + i, qb = q + 2 < KQ ? q + 2 : KQ - 1, qa = q + 1 < KQ ? q + 1 : KQ - 1;
+        bb[(i + 2) % NB][0] = wb[qb * wstep];
+        bb[(i + 2) % NB][1] = wb[qb * wstep + 64];
+        aa[(K0 + i + 1) % 2] = *reinterpret_cast<const float4*>(ab + 8 * qa);
+        MFMA8(aa[(K0 + i) % 2], bb[i % NB][0], bb[i % NB][1])
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) {   // the last (KQ - K0) % 6 groups
+      const int q = q0 + i;
+      if (q < KQ) {
+        const int qb = q + 2 < KQ ? q + 2 : KQ - 1, qa = q + 1 < KQ ? q + 1 : KQ - 1;
+        bb[(i + 2) % NB][0] = wb[qb * wstep];
+        bb[(i + 2) % NB][1] = wb[qb * wstep + 64];
+        aa[(K0 + i + 1) % 2] = *reinterpret_cast<const float4*>(ab + 8 * qa);
+        MFMA8(aa[(K0 + i) % 2], bb[i % NB][0], bb[i % NB][1])
+      }
     }
   }
-  // C/D of a 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  // C/D of a 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a store instruction writes
+  // two 128-byte row segments.  Nothing waits for these stores (a consumer has no load in its queue behind them).
+  const long long row0 = (long long)tile * BM;
   const int col0 = 32 * nt0 + l31, col1 = col0 + 32;
+  const bool whole = row0 + BM <= a.n_pad;
+  float* y0 = a.y + (row0 + 4 * h) * a.ldy;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    const int rl = (i & 3) + 8 * (i >> 2) + 4 * h;
+    const int rl = (i & 3) + 8 * (i >> 2);
     float u0 = acc0[i], u1 = acc1[i];
     if (a.relu_out) u0 = fmaxf(u0, 0.f), u1 = fmaxf(u1, 0.f);
-    O[rl * ldo + col0] = u0;
-    O[rl * ldo + col1] = u1;
+    if ((a.dbg & 8) && u0 != 12345.678f) continue;
+    if (whole || row0 + 4 * h + rl < a.n_pad) {
+      if (col0 < a.out) y0[(long long)rl * a.ldy + col0] = u0;
+      if (col1 < a.out) y0[(long long)rl * a.ldy + col1] = u1;
+    }
   }
 }
 #undef MFMA8
 
+// the operand tile itself, if the caller wants it (the backward's weight-gradient GEMM reads it): LDS -> cat, 8 rows per
+// consumer wave
+__device__ __forceinline__ void store_operand(const FwdArgs& a, int t, int tile, int wave, int lane, const float* Abuf) {
+  if (!a.cat || (a.dbg & 64)) return;
+  const int lda = a.lda;
+  const float* A = Abuf + ((t - 1) & 1) * BM * lda;
+  const long long row0 = (long long)tile * BM;
+  const int q4 = (2 * a.H) >> 2;   // float4 per row
+  for (int e = lane; e < 8 * q4; e += 64) {
+    const int rl = 8 * wave + e / q4, c = (e % q4) * 4;
+    if (row0 + rl < a.n_pad)
+      *reinterpret_cast<float4*>(a.cat + (row0 + rl) * a.ldc + c) = *reinterpret_cast<const float4*>(A + rl * lda + c);
+  }
+}
+
+// KS k-groups of W stationary in the consumers' registers, the next KL in LDS; STREAM: the layer has more, streamed from L2
+template <int KS, int KL, bool STREAM>
 __global__ __launch_bounds__(TBP) void k_sage_fwd_mfma(const FwdArgs a) {
   extern __shared__ float4 smem4[];
   float* Abuf = reinterpret_cast<float*>(smem4);               // [2][BM][lda]
-  float* Obuf = Abuf + 2 * BM * a.lda;                         // [2][BM][ldo]
-  int* Ibuf = reinterpret_cast<int*>(Obuf + 2 * BM * a.ldo);   // [2][BM][IDXW]
+  int* Ibuf = reinterpret_cast<int*>(Abuf + 2 * BM * a.lda);   // [3][BM][IDXW]
+  float4* Wl = reinterpret_cast<float4*>(Ibuf + 4 * BM * IDXW);   // [KL][NCONS][2][64]  (16-byte aligned: 4 x 32 x 18 ints)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = gridDim.x, b = blockIdx.x;
   const int S = (a.n_tiles - b + G - 1) / G;   // this workgroup's tiles: b, b + G, ...
+  // the longest row among this workgroup's tiles decides the producers' path (one look at the row pointers; uniform)
+  __shared__ int s_maxdeg;
+  if (tid == 0) s_maxdeg = 0;
+  __syncthreads();
   if (wave >= NCONS) {
-    ProdState st;
-    st.p_e0 = 0, st.p_deg = 0, st.p_sid = -1, st.i_raw = -1, st.i_sid = -1, st.i_deg = 0;
     const int j = tid - 64 * NCONS;
-    for (int t = -3; t <= S + 1; t++) {
-      const unsigned s0 = (unsigned)__builtin_amdgcn_s_memrealtime();
-      producer_step(a, t, S, b, G, j, Abuf, Obuf, Ibuf, st);
-      const unsigned s1 = (unsigned)__builtin_amdgcn_s_memrealtime();
-      __syncthreads();
-      if ((a.dbg & 64) && j == 0 && t + 3 < 64) {   // diagnostics: 10 ns ticks of this step, into the (unused) cat buffer
-        unsigned* o = reinterpret_cast<unsigned*>(a.cat) + ((b * 64 + (t + 3)) * 2 + 1) * 4;
-        o[0] = s0, o[1] = s1, o[2] = (unsigned)__builtin_amdgcn_s_memrealtime(), o[3] = S;
-      }
+    int md = 0;
+    for (int i = j; i < S * BM; i += PT) {
+      const long long r = (long long)(b + (long long)(i / BM) * G) * BM + (i % BM);
+      if (r < a.n) md = max(md, a.indptr[r + 1] - a.indptr[r]);
+    }
+    if (md > 0) atomicMax(&s_maxdeg, md);
+    // staged rows start as "no self row, no edges" (the prologue steps read them)
+    for (int i = j; i < 3 * BM * IDXW; i += PT) Ibuf[i] = (i % IDXW) == 0 ? 0 : -1;
+  }
+  __syncthreads();
+  if (wave >= NCONS) {
+    const int j = tid - 64 * NCONS;
+    const int md = s_maxdeg;
+    if (a.dbg & 2048) __builtin_amdgcn_s_setprio(3);
+    ProdState st;
+    st.p_e0 = 0, st.p_deg = 0, st.p_sid = -1, st.i_sid = -1, st.i_deg = 0;
+#pragma unroll
+    for (int k = 0; k < NSL; k++) st.i_raw[k] = -1;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+      for (int e = 0; e < 2 * (EC + 1); e++) st.r[k][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.H > 128 || md > 3 * EC || md > EMAX || (a.dbg & 4096)) producer_loop<0, false>(a, S, b, G, j, Abuf, Ibuf, st);
+    else if (a.relu_in) {
+      if (md <= EC) producer_loop<1, true>(a, S, b, G, j, Abuf, Ibuf, st);
+      else if (md <= 2 * EC) producer_loop<2, true>(a, S, b, G, j, Abuf, Ibuf, st);
+      else producer_loop<3, true>(a, S, b, G, j, Abuf, Ibuf, st);
+    } else {
+      if (md <= EC) producer_loop<1, false>(a, S, b, G, j, Abuf, Ibuf, st);
+      else if (md <= 2 * EC) producer_loop<2, false>(a, S, b, G, j, Abuf, Ibuf, st);
+      else producer_loop<3, false>(a, S, b, G, j, Abuf, Ibuf, st);
     }
   } else {
-    __builtin_amdgcn_s_setprio(2);
+    if (!(a.dbg & 1024)) __builtin_amdgcn_s_setprio(2);
     const int nt0 = 2 * wave;
     const bool work = nt0 < a.NTp && !(a.dbg & 2);   // (narrow layers: fewer than 8 n-tiles)
-    ConsRegs cr;
-    cr.bv0 = cr.bv1 = 0.f;
-    cr.rb[0][0] = cr.rb[0][1] = cr.rb[1][0] = cr.rb[1][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (work) {
-      const float4* wb = a.wp + (long long)nt0 * 64 + lane;
+    float4 ws[KS > 0 ? KS : 1][2];
+    float bv0 = 0.f, bv1 = 0.f;
+    {
+      // (a wave without columns of its own reads n-tile 0: the loads stay unconditional)
+      const float4* wb = a.wp + (long long)(work ? nt0 : 0) * 64 + lane;
       const long long wstep = (long long)a.NTp * 64;
-      const int KQ = (2 * a.H) / 8;
-      cr.rb[0][0] = wb[0], cr.rb[0][1] = wb[64];
-      if (KQ > 1) cr.rb[1][0] = wb[wstep], cr.rb[1][1] = wb[wstep + 64];
+#pragma unroll
+      for (int q = 0; q < KS; q++) ws[q][0] = wb[q * wstep], ws[q][1] = wb[q * wstep + 64];
+#pragma unroll
+      for (int k = 0; k < KL; k++) {   // this wave's own slice of the LDS part (read back by this wave only)
+        Wl[k * (NCONS * 128) + wave * 128 + lane] = wb[(KS + k) * wstep];
+        Wl[k * (NCONS * 128) + wave * 128 + 64 + lane] = wb[(KS + k) * wstep + 64];
+      }
+      if (KS == 0) ws[0][0] = ws[0][1] = make_float4(0.f, 0.f, 0.f, 0.f);
       const int col0 = 32 * nt0 + (lane & 31), col1 = col0 + 32;
-      if (a.bias && col0 < a.out) cr.bv0 = a.bias[col0];
-      if (a.bias && col1 < a.out) cr.bv1 = a.bias[col1];
+      if (a.bias && col0 < a.out) bv0 = a.bias[col0];
+      if (a.bias && col1 < a.out) bv1 = a.bias[col1];
     }
-    for (int t = -3; t <= S + 1; t++) {
+    for (int t = -4; t <= S + 1; t++) {
       const unsigned s0 = (unsigned)__builtin_amdgcn_s_memrealtime();
-      if (work && t >= 1 && t <= S) consumer_step(a, t, wave, lane, Abuf, Obuf, cr);
+      if (t >= 1 && t <= S) {
+        if (work) consumer_step<KS, KL, STREAM>(a, t, b + (t - 1) * G, wave, lane, Abuf, Wl, ws, bv0, bv1);
+        store_operand(a, t, b + (t - 1) * G, wave, lane, Abuf);
+      }
       const unsigned s1 = (unsigned)__builtin_amdgcn_s_memrealtime();
       __syncthreads();
-      if ((a.dbg & 64) && tid == 0 && t + 3 < 64) {
-        unsigned* o = reinterpret_cast<unsigned*>(a.cat) + ((b * 64 + (t + 3)) * 2 + 0) * 4;
+      if ((a.dbg & 64) && tid == 0 && t + 4 < 64) {
+        unsigned* o = reinterpret_cast<unsigned*>(a.cat) + ((b * 64 + (t + 4)) * 2 + 0) * 4;
         o[0] = s0, o[1] = s1, o[2] = (unsigned)__builtin_amdgcn_s_memrealtime(), o[3] = S;
       }
     }
@@ -383,8 +495,28 @@ __global__ __launch_bounds__(TBP) void k_sage_fwd_mfma(const FwdArgs a) {
 
 inline int lda_for(int H) { return 2 * H + 4; }  // 2 H is a multiple of 8, so (2 H + 4) / 4 is odd
 inline int ntp_for(int out) { return ((out + 31) / 32 + 1) & ~1; }
-inline size_t lds_for(int H, int out) {
-  return (size_t)2 * BM * (lda_for(H) + ntp_for(out) * 32) * sizeof(float) + (size_t)2 * BM * IDXW * sizeof(int);
+inline size_t lds_for(int H, int out, int KL) {
+  return (size_t)2 * BM * lda_for(H) * sizeof(float) + (size_t)4 * BM * IDXW * sizeof(int) + 64 +
+         (size_t)KL * NCONS * 128 * sizeof(float4);
+}
+// how W is held: KS k-groups in the consumers' registers (8 registers each), KL in LDS (8 KB each), the rest streamed.
+// in = 100 (25 groups): 19 + 6, nothing streamed.
+inline void split_for(int KQ, int& KS, int& KL) {
+  KS = KQ == 25 ? 19 : KQ == 24 ? 18 : KQ >= 16 ? 16 : 0;
+  KL = (KQ == 24 || KQ == 25) ? 6 : 0;
+}
+
+template <int KS, int KL, bool STREAM>
+int launch(const FwdArgs& a, unsigned grid, size_t lds, hipStream_t st) {
+  static size_t attr_lds = 48 * 1024;   // (more dynamic LDS than the default limit must be asked for, once per size)
+  if (lds > attr_lds) {
+    if (hipFuncSetAttribute((const void*)k_sage_fwd_mfma<KS, KL, STREAM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return CSL_E_HIP;
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((k_sage_fwd_mfma<KS, KL, STREAM>), dim3(grid), dim3(TBP), lds, st, a);
+  return hipGetLastError() == hipSuccess ? CSL_OK : CSL_E_HIP;
 }
 
 }  // namespace
@@ -392,8 +524,10 @@ inline size_t lds_for(int H, int out) {
 extern "C" {
 
 int64_t csl_sage_fwd_mfma_scratch(int32_t H, int32_t out) {
-  if (H < 4 || H % 4 != 0 || out < 1 || out > 256 || lds_for(H, out) > 160 * 1024) return CSL_E_INVALID;
-  return (int64_t)(2 * H / 8) * ntp_for(out) * 64 * 4;
+  int KS, KL;
+  split_for(2 * H / 8, KS, KL);
+  if (H < 4 || H % 4 != 0 || out < 1 || out > 256 || lds_for(H, out, KL) > 160 * 1024 - 64) return CSL_E_INVALID;
+  return (int64_t)(2 * H / 8) * ntp_for(out) * 64 * 4 + 128;   // packed W + a zero row
 }
 
 int csl_sage_fwd_mfma_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
@@ -406,8 +540,10 @@ int csl_sage_fwd_mfma_f32(const int32_t* indptr, const int32_t* indices, const i
     return CSL_E_INVALID;
   if (n > 0 && (!indptr || !self_ids || !x || ldx < H || ldx % 4 != 0 || ((uintptr_t)x & 15))) return CSL_E_INVALID;
   if (cat && (ldc < 2 * (int64_t)H || ldc % 4 != 0 || ((uintptr_t)cat & 15))) return CSL_E_INVALID;
-  const size_t lds = lds_for(H, out);
-  if (lds > 160 * 1024) return CSL_E_INVALID;
+  int KS, KL;
+  split_for(2 * H / 8, KS, KL);
+  const size_t lds = lds_for(H, out, KL);
+  if (lds > 160 * 1024 - 64) return CSL_E_INVALID;
   if ((n_pad + BM - 1) / BM > 0x7fffffffLL / BM) return CSL_E_INVALID;
   int dbg = 0;
   {
@@ -424,29 +560,25 @@ int csl_sage_fwd_mfma_f32(const int32_t* indptr, const int32_t* indices, const i
   const int NTp = ntp_for(out), KQ = 2 * H / 8;
   hipStream_t st = (hipStream_t)stream;
   const long long nw = (long long)KQ * NTp * 64;
-  hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, W, (long long)ldw, (int)out, KQ, NTp,
+  hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((nw + 32 + 255) / 256)), dim3(256), 0, st, W, (long long)ldw, (int)out, KQ, NTp,
                      reinterpret_cast<float4*>(wpack));
   FwdArgs a;
   a.indptr = indptr, a.indices = indices, a.self_ids = self_ids, a.rowmap = rowmap;
-  a.x = x, a.ldx = ldx, a.wp = reinterpret_cast<const float4*>(wpack), a.bias = bias;
+  a.x = x, a.ldx = ldx, a.wp = reinterpret_cast<const float4*>(wpack), a.zero = wpack + nw * 4, a.bias = bias;
   a.cat = cat, a.ldc = ldc, a.y = y, a.ldy = ldy, a.n = n, a.n_pad = n_pad;
-  a.H = H, a.out = out, a.NTp = NTp, a.relu_in = relu_in, a.relu_out = relu_out, a.lda = lda_for(H), a.ldo = NTp * 32;
+  a.H = H, a.out = out, a.NTp = NTp, a.relu_in = relu_in, a.relu_out = relu_out, a.lda = lda_for(H);
   a.n_tiles = (int)((n_pad + BM - 1) / BM);
-  a.vec_y = (out % 4 == 0 && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0) ? 1 : 0;
   a.indptr_ld = (indptr && n > 0) ? indptr : reinterpret_cast<const int*>(wpack);
   a.self_ld = (self_ids && n > 0) ? self_ids : reinterpret_cast<const int*>(wpack);
   a.indices_ld = indices ? indices : reinterpret_cast<const int*>(wpack);
   a.rowmap_ld = rowmap ? rowmap : reinterpret_cast<const int*>(wpack);
   a.dbg = dbg;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_sage_fwd_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return CSL_E_HIP;
-    attr_set = true;
-  }
   const unsigned grid = (unsigned)(a.n_tiles < n_cu ? a.n_tiles : n_cu);
-  hipLaunchKernelGGL(k_sage_fwd_mfma, dim3(grid), dim3(TBP), lds, st, a);
-  return hipGetLastError() == hipSuccess ? CSL_OK : CSL_E_HIP;
+  if (KQ == 25) return launch<19, 6, false>(a, grid, lds, st);
+  if (KQ == 24) return launch<18, 6, false>(a, grid, lds, st);
+  if (KQ == 16) return launch<16, 0, false>(a, grid, lds, st);
+  if (KQ > 16) return launch<16, 0, true>(a, grid, lds, st);
+  return launch<0, 0, true>(a, grid, lds, st);
 }
 
 }  // extern "C"

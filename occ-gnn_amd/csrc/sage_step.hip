@@ -21,6 +21,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "cslicer_aggr.h"
 #include "cslicer_hip.h"
@@ -47,6 +48,7 @@ struct Layout {
   int64_t bpart[CSL_MAX_LAYERS];    // [blocks][out]: per-block column sums behind gb_k (k < L-1: from layer k+1's gather)
   int64_t bblocks[CSL_MAX_LAYERS];
   int64_t lpart, lblocks;           // [blocks]: the loss
+  int64_t wpack;                    // W_0 in MFMA operand order (csl_sage_fwd_mfma_f32), -1: the deepest layer is not fused
   bool slabbed[CSL_MAX_LAYERS];
   bool top_cols;                    // the softmax pass also leaves the top layer's bias column sums
   int64_t g, scratch, total;
@@ -97,6 +99,12 @@ bool lay_out(int32_t L, const int32_t* dims, const csl_sage_slice* sl, int64_t r
     at += o.top_cols ? 0 : up4(sl[k].n_out * C);
   }
   o.scratch = at, at += up4(scratch);
+  {
+    // the deepest layer as ONE kernel (gather -> fp32 MFMA -> bias + ReLU) where its widths allow
+    const int64_t wp = getenv("CSLICER_NO_MFMA_FWD") ? -1 : csl_sage_fwd_mfma_scratch(dims[0], dims[1]);
+    o.wpack = wp > 0 ? at : -1;
+    if (wp > 0) at += up4(wp);
+  }
   o.total = at;
   return true;
 }
@@ -155,6 +163,14 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
     const int32_t in = dims[k], out = dims[k + 1];
     const int64_t m = sl[k].n_out, mp = o.mp[k];
     const float* x = k == 0 ? feat : ws + o.y[k - 1];
+    if (k == 0 && o.wpack >= 0) {
+      // gather [self | mean] into LDS, multiply on the fp32 matrix cores, bias + ReLU on the way out; the operand is
+      // also written (the weight gradient reads it), but never read back by the forward
+      STEP(csl_sage_fwd_mfma_f32(sl[0].indptr, sl[0].indices, sl[0].self_ids_in, feat_rows, feat, ldf, weights[0],
+                                 2 * (int64_t)in, biases[0], m, mp, in, out, 0, L > 1 ? 1 : 0, ws + o.cat[0],
+                                 2 * (int64_t)in, ws + o.y[0], out, ws + o.wpack, stream));
+      continue;
+    }
     STEP(csl_sage_cat_f32(sl[k].indptr, sl[k].indices, sl[k].self_ids_in, nullptr, nullptr, k == 0 ? feat_rows : nullptr, x,
                           k == 0 ? ldf : (int64_t)in, nullptr, 0, m, mp, ws + o.cat[k], 2 * (int64_t)in, in, 0, stream));
     STEP(csl_gemm_f32(0, 1, mp, out, 2 * (int64_t)in, ws + o.cat[k], 2 * (int64_t)in, 0, weights[k], 2 * (int64_t)in, 0,

@@ -79,10 +79,10 @@ def main():
         _, cat = fused(True)
         w = cat.flatten()[:256 * 64 * 2 * 4].view(torch.int32).cpu().numpy().astype(np.int64).reshape(256, 64, 2, 4) & 0xFFFFFFFF
         S = int(w[0, 0, 0, 3])
-        nst = S + 5
+        nst = S + 6
         t0 = w[:, 0, :, 0].min()
         print("steps per workgroup %d (tiles %d); kernel span %.1f us" % (nst, S, (w[:, :nst, :, 2].max() - t0) / 100))
-        for role, name in ((0, "consumer"), (1, "producer")):
+        for role, name in ((0, "consumer"),):
             work = (w[:, :nst, role, 1] - w[:, :nst, role, 0]) / 100.0
             wait = (w[:, :nst, role, 2] - w[:, :nst, role, 1]) / 100.0
             print("  %s: work per step (us, median over workgroups): %s" % (name, " ".join("%.2f" % x for x in np.median(work, 0))))

@@ -78,7 +78,7 @@ def _run(aggr, case, n, n_pad, relu_in, relu_out, want_cat):
                               relu_in=relu_in, relu_out=relu_out, want_cat=want_cat)
 
 
-@pytest.mark.parametrize("H,out", [(4, 1), (8, 32), (100, 256), (100, 47), (104, 200), (128, 64), (128, 256), (36, 33), (256, 64)])
+@pytest.mark.parametrize("H,out", [(4, 1), (8, 32), (100, 256), (100, 47), (104, 200), (128, 64), (128, 256), (36, 33), (256, 64), (256, 256), (96, 256)])
 def test_operand_layout_exact_on_integers(aggr, H, out):
     """Small integers: every product and partial sum is exact in fp32, so the fused kernel must reproduce the float64
     result bit for bit wherever the mean is exact (degrees 0, 1, 2, 4: divisions by powers of two)."""
@@ -102,6 +102,9 @@ def test_operand_layout_exact_on_integers(aggr, H, out):
     (100, 256, 5, False, True, 5000),      # the deepest layer of the products step: feature table through in_nodes
     (100, 256, 20, False, True, None),     # rows longer than the 8 edges requested together
     (128, 256, 10, True, True, None),      # a middle layer: previous pre-activation output, ReLU on the way in
+    (256, 256, 10, True, True, None),      # ... at the bench's hidden width (rows wider than 128 columns: generic producers)
+    (100, 256, 12, False, True, 4000),     # two edge passes per row
+    (100, 256, 16, False, True, 4000),     # three
     (100, 256, 40, False, False, 3000),    # rows longer than the 16 staged entries: the index arrays are read directly
     (256, 47, 15, True, False, None),      # the top layer: 47 classes (two n-tiles, the second one partial)
     (4, 3, 3, False, False, 97),
@@ -149,5 +152,5 @@ def test_rejects_unsupported_widths(aggr):
         aggr.sage_fwd_mfma(x, sid, ip, ix, torch.zeros(4, 12, device="cuda"), None, 1, 1)       # in % 4 != 0
     with pytest.raises(ValueError):
         aggr.sage_fwd_mfma(torch.zeros(8, 8, device="cuda"), sid, ip, ix, torch.zeros(300, 16, device="cuda"), None, 1, 1)
-    with pytest.raises(ValueError):      # two operand tiles + two result tiles of this width do not fit a CU's 160 KB of LDS
-        aggr.sage_fwd_mfma(torch.zeros(8, 256, device="cuda"), sid, ip, ix, torch.zeros(256, 512, device="cuda"), None, 1, 1)
+    with pytest.raises(ValueError):      # two operand tiles of this width do not fit a CU's 160 KB of LDS
+        aggr.sage_fwd_mfma(torch.zeros(8, 320, device="cuda"), sid, ip, ix, torch.zeros(256, 640, device="cuda"), None, 1, 1)
