@@ -46,7 +46,16 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// raw buffer descriptors (stride 0) for the consumers' stores: 32-bit byte offsets (one lane offset per tile + the row as a
+// scalar offset: no 64-bit vector arithmetic per store), and an offset beyond num_records stores nothing.
+// (Loads do not go this way: __builtin_amdgcn_raw_buffer_load_b128 is lowered to a ONE-dword load by ROCm 7.2's clang 22.)
+constexpr unsigned SRD_FLAGS = 0x00020000;
+constexpr unsigned OOB = 0xF0000000u;   // beyond every buffer this path accepts (< 3.75 GB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, SRD_FLAGS);
+}
 constexpr int NCONS = 4;                    // consumer (MFMA) waves: one per SIMD
 constexpr int NPROD = 4;                    // producer (gather / store) waves: one per SIMD
 constexpr int TBP = 64 * (NCONS + NPROD);   // 512 threads: two waves per SIMD, 256 registers each
@@ -79,6 +88,8 @@ struct FwdArgs {
   const int* indices_ld;
   const int* self_ld;
   const int* rowmap_ld;
+  unsigned y_bytes;   // n_pad * ldy * 4 if < 4 GB, else 0
+  unsigned cat_bytes;
   int dbg;            // diagnostics (CSLICER_MFMA_DBG): 1 = no feature loads, 2 = no multiply, 64 = step stamps into cat
 };
 
@@ -376,6 +387,24 @@ __device__ __forceinline__ void consumer_step(const FwdArgs& a, int t, int tile,
   // two 128-byte row segments.  Nothing waits for these stores (a consumer has no load in its queue behind them).
   const long long row0 = (long long)tile * BM;
   const int col0 = 32 * nt0 + l31, col1 = col0 + 32;
+  if (a.y_bytes) {
+    // 32-bit buffer addressing: one lane offset per tile, the row of each register as a scalar offset; a row beyond
+    // n_pad is beyond the descriptor's range and is not stored
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y, a.y_bytes);
+    const unsigned base = ((unsigned)(row0 + 4 * h) * (unsigned)a.ldy + (unsigned)col0) * 4u;
+    const unsigned v0 = col0 < a.out ? base : OOB, v1 = col1 < a.out ? base + 128u : OOB;
+    const unsigned rowb = (unsigned)a.ldy * 4u;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int rl = (i & 3) + 8 * (i >> 2);
+      float u0 = acc0[i], u1 = acc1[i];
+      if (a.relu_out) u0 = fmaxf(u0, 0.f), u1 = fmaxf(u1, 0.f);
+      if ((a.dbg & 8) && u0 != 12345.678f) continue;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, u0), ry, v0, rl * rowb, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, u1), ry, v1, rl * rowb, 0);
+    }
+    return;
+  }
   const bool whole = row0 + BM <= a.n_pad;
   float* y0 = a.y + (row0 + 4 * h) * a.ldy;
 #pragma unroll
@@ -383,7 +412,6 @@ __device__ __forceinline__ void consumer_step(const FwdArgs& a, int t, int tile,
     const int rl = (i & 3) + 8 * (i >> 2);
     float u0 = acc0[i], u1 = acc1[i];
     if (a.relu_out) u0 = fmaxf(u0, 0.f), u1 = fmaxf(u1, 0.f);
-    if ((a.dbg & 8) && u0 != 12345.678f) continue;
     if (whole || row0 + 4 * h + rl < a.n_pad) {
       if (col0 < a.out) y0[(long long)rl * a.ldy + col0] = u0;
       if (col1 < a.out) y0[(long long)rl * a.ldy + col1] = u1;
@@ -400,6 +428,22 @@ __device__ __forceinline__ void store_operand(const FwdArgs& a, int t, int tile,
   const float* A = Abuf + ((t - 1) & 1) * BM * lda;
   const long long row0 = (long long)tile * BM;
   const int q4 = (2 * a.H) >> 2;   // float4 per row
+  if (a.cat_bytes) {
+    // a row per trip, lanes across it: no division, the row as a scalar offset, rows beyond n_pad out of range
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cat, a.cat_bytes);
+    const unsigned rowb = (unsigned)a.ldc * 4u;
+    for (int c4 = lane; c4 < q4; c4 += 64) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int rl = 8 * wave + i;
+        const float4 v = *reinterpret_cast<const float4*>(A + rl * lda + c4 * 4);
+        const u32x4 u = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y), __builtin_bit_cast(unsigned, v.z),
+                         __builtin_bit_cast(unsigned, v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(u, rc, (unsigned)c4 * 16u, (unsigned)(row0 + rl) * rowb, 0);
+      }
+    }
+    return;
+  }
   for (int e = lane; e < 8 * q4; e += 64) {
     const int rl = 8 * wave + e / q4, c = (e % q4) * 4;
     if (row0 + rl < a.n_pad)
@@ -572,6 +616,12 @@ int csl_sage_fwd_mfma_f32(const int32_t* indptr, const int32_t* indices, const i
   a.self_ld = (self_ids && n > 0) ? self_ids : reinterpret_cast<const int*>(wpack);
   a.indices_ld = indices ? indices : reinterpret_cast<const int*>(wpack);
   a.rowmap_ld = rowmap ? rowmap : reinterpret_cast<const int*>(wpack);
+  {
+    const unsigned long long yb = (unsigned long long)n_pad * (unsigned long long)ldy * 4ull;
+    const unsigned long long cb = cat ? (unsigned long long)n_pad * (unsigned long long)ldc * 4ull : 0ull;
+    a.y_bytes = yb < OOB ? (unsigned)yb : 0u;
+    a.cat_bytes = (cb > 0 && cb < OOB) ? (unsigned)cb : 0u;
+  }
   a.dbg = dbg;
   const unsigned grid = (unsigned)(a.n_tiles < n_cu ? a.n_tiles : n_cu);
   if (KQ == 25) return launch<19, 6, false>(a, grid, lds, st);
