@@ -588,27 +588,59 @@ def main():
         t_e2e = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)
         work = tr.step_work(args.e2e_steps) if args.e2e_model == "sage" else None
         tr_native = getattr(tr, "native", None) is not None or getattr(tr, "native_rank", None) is not None
+        # ---- per-group device time of the step's own kernels: one more round with HIP events around every launch of the
+        # native step (csl_sage_step_timing), outside the timed region.  The fractions below are work of a group / the
+        # time of THAT group's kernels -- what the kernels sustain -- not / the step's wall time.
+        groups = None
+        if work is not None and getattr(tr, "native", None) is not None and world == 1:
+            from cslicer import aggr
+            n_t = args.e2e_streams
+            aggr.step_timing(True)
+            tr.reset_units()
+            tr.run(n_t, first_batch=after)
+            torch.cuda.synchronize()
+            groups = aggr.step_timing_read()
+            aggr.step_timing(False)
+            work_t = tr.step_work(n_t)
+        fused = bool(getattr(tr, "fused_deepest_layer", lambda: False)())
         tr.close()
         roof = None
         if work is not None:
-            # this rank's algorithmic work per step over the step's wall time: what fraction of the chip's peaks the
-            # WHOLE step sustains (a step is GEMMs + HBM-bound aggregation + small kernels one after the other, so
-            # the two fractions add up to well below 1; the per-kernel split is profiles/r2_e2e/summary.md)
             step_s = t_e2e / args.e2e_steps
-            roof = {
-                "gemm": {"bound": "mfma", "flops_per_step": work["gemm_flops"], "achieved": work["gemm_flops"] / step_s / 1e12,
-                         "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": work["gemm_flops"] / step_s / 1e12 / FP32_MFMA_PEAK_TFS},
-                "aggregation": {"bound": "hbm", "bytes_per_step": work["aggregation_bytes"],
-                                "achieved": work["aggregation_bytes"] / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": work["aggregation_bytes"] / step_s / 1e9 / HBM_PEAK_GBS},
-                "note": "algorithmic work of rank 0's step / the step's wall time; kernel-level split and GPU-busy "
-                        "fraction: profiles/r2_e2e/summary.md (rocprofv3 --kernel-trace --marker-trace)",
-            }
+            roof = {"whole_step": {
+                "gemm_TFLOPs": work["gemm_flops"] / step_s / 1e12, "aggregation_GBs": work["aggregation_bytes"] / step_s / 1e9,
+                "note": "algorithmic work of rank 0's step / the step's WALL time (GEMMs, HBM-bound gathers and small "
+                        "kernels run one after the other, so these are not kernel rates)"}}
+            if groups is not None:
+                us = {g: 1e3 * groups[g][0] / n_t for g in groups}
+                roof["us_per_step"] = us
+                roof["launches_per_step"] = {g: groups[g][1] / n_t for g in groups}
+                if us["gemm"] > 0:
+                    a_ = work_t["gemm"]["flops"] / (us["gemm"] * 1e-6) / 1e12
+                    roof["gemm"] = {"bound": "mfma", "what": "library fp32 GEMMs (hipBLASLt)", "flops_per_step": work_t["gemm"]["flops"],
+                                    "achieved": a_, "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": a_ / FP32_MFMA_PEAK_TFS}
+                if us["fused_forward"] > 0:
+                    a_ = work_t["fused_forward"]["flops"] / (us["fused_forward"] * 1e-6) / 1e12
+                    b_ = work_t["fused_forward"]["bytes"] / (us["fused_forward"] * 1e-6) / 1e9
+                    roof["fused_forward"] = {"bound": "mfma", "what": "csl_sage_fwd_mfma_f32: gather -> fp32 MFMA -> bias + ReLU, deepest layer",
+                                             "flops_per_step": work_t["fused_forward"]["flops"], "achieved": a_,
+                                             "peak": FP32_MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": a_ / FP32_MFMA_PEAK_TFS,
+                                             "hbm_bytes_per_step": work_t["fused_forward"]["bytes"], "hbm_GBs": b_,
+                                             "hbm_frac": b_ / HBM_PEAK_GBS}
+                if us["aggregation"] > 0:
+                    b_ = work_t["aggregation"]["bytes"] / (us["aggregation"] * 1e-6) / 1e9
+                    roof["aggregation"] = {"bound": "hbm", "what": "csl_sage_cat_f32 / csl_sage_cat_bwd_t_f32 (every row counted once)",
+                                           "bytes_per_step": work_t["aggregation"]["bytes"], "achieved": b_, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": b_ / HBM_PEAK_GBS}
+                roof["note"] = ("work of a kernel group / device time of that group's kernels, HIP events around every launch of "
+                                "the native step in a separate pass of %d steps (csl_sage_step_timing); PMC traffic of the "
+                                "aggregation kernels: profiles/r3_e2e/" % n_t)
         return {
             "roofline": roof,
             # one native call per minibatch (csl_sage_fwd_bwd_f32, direct hipBLASLt GEMMs timed per shape) or the
             # kernels issued from Python through torch autograd (then with torch's GEMMs and these selections)
             "native_step": tr_native,
+            "fused_deepest_layer": fused,
             "exchange_overlap": bool(args.e2e_overlap and world > 1 and args.e2e_model == "sage"),
             "tuned_gemm_selections": bool(tuned) and not tr_native,
             "iters_per_sec": args.e2e_steps / t_e2e, "ms_per_iter": 1e3 * t_e2e / args.e2e_steps,

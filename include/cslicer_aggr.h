@@ -270,6 +270,20 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
                          float* grads, float* loss, float* workspace, int64_t workspace_floats, void* stream);
 const char* csl_sage_last_error(void);
 
+/* Diagnostics: device time of csl_sage_fwd_bwd_f32's launches by group, measured with HIP events around every launch on
+ * the step's own stream (what bench.py's e2e.roofline is computed from: work of a group / time of that group's kernels,
+ * not / the step's wall time).  csl_sage_step_timing(1) switches the recording on (it costs two event records per launch:
+ * a measurement pass, not the timed region), csl_sage_step_timing_read waits for the recorded launches, returns the
+ * milliseconds and launch counts accumulated since the last read in ms[CSL_STEP_GROUPS] / launches[CSL_STEP_GROUPS] and
+ * clears them. */
+#define CSL_STEP_FUSED_FWD 0    /* csl_sage_fwd_mfma_f32 (its W re-pack included) */
+#define CSL_STEP_GEMM 1         /* csl_gemm_f32: the library GEMMs */
+#define CSL_STEP_AGGREGATION 2  /* csl_sage_cat_f32, csl_sage_cat_bwd_t_f32 / csl_sage_cat_bwd_f32, csl_relu_bwd_colsum_f32 */
+#define CSL_STEP_OTHER 3        /* loss, second stages of the reductions */
+#define CSL_STEP_GROUPS 4
+int csl_sage_step_timing(int32_t enable);
+int csl_sage_step_timing_read(double* ms, int64_t* launches);
+
 /* ---- one rank of the SPLIT-PARALLEL training step (python/train.py + dist_sageconv.py:42-84 on several GPUs) ----
  * Part g of P, one process per part: forward, loss over the seeds this part owns and backward of the GraphSAGE model
  * for one minibatch as one call.  Per layer the partial sums of the out rows that PEERS own are sent to their owners

@@ -22,7 +22,8 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_sum_slabs_f32", "csl_sage_fwd_bwd_f32", "csl_sage_fwd_bwd_workspace", "csl_sage_last_error",
            "csl_gemm_save_plans", "csl_gemm_load_plans", "csl_softmax_ce_partial_f32", "csl_reduce_multi_f32",
            "csl_sage_rank_fwd_bwd_f32", "csl_sage_rank_workspace", "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch",
-           "csl_gat_bwd_t_f32", "csl_sage_fwd_mfma_f32", "csl_sage_fwd_mfma_scratch"]
+           "csl_gat_bwd_t_f32", "csl_sage_fwd_mfma_f32", "csl_sage_fwd_mfma_scratch", "csl_sage_step_timing",
+           "csl_sage_step_timing_read"]
 _ready = False
 
 
@@ -77,6 +78,8 @@ def _lib():
         L.csl_gat_finish_bwd_scratch.argtypes = [i64, i32, i32]
         L.csl_gat_finish_bwd_scratch.restype = i64
         L.csl_gemm_load_plans.argtypes = [C.c_char_p]
+        L.csl_sage_step_timing.argtypes = [i32]
+        L.csl_sage_step_timing_read.argtypes = [vp, vp]
         L.csl_sage_fwd_mfma_scratch.argtypes = [i32, i32]
         L.csl_sage_fwd_mfma_scratch.restype = i64
         L.csl_sage_fwd_mfma_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, vp, i64,
@@ -359,6 +362,22 @@ class SageSlice(C.Structure):
     _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("self_ids_in", C.c_void_p),
                 ("t_indptr", C.c_void_p), ("t_indices", C.c_void_p), ("n_out", C.c_int64), ("n_in", C.c_int64),
                 ("t_max_len", C.c_int64)]
+
+
+STEP_GROUPS = ("fused_forward", "gemm", "aggregation", "other")
+
+
+def step_timing(enable):
+    """switch the per-group HIP-event timing of csl_sage_fwd_bwd_f32 on or off (cslicer_aggr.h)"""
+    _chk(_lib().csl_sage_step_timing(1 if enable else 0), "csl_sage_step_timing")
+
+
+def step_timing_read():
+    """{group: (milliseconds, launches)} accumulated since the last read (waits for the recorded launches)"""
+    ms = (C.c_double * len(STEP_GROUPS))()
+    n = (C.c_int64 * len(STEP_GROUPS))()
+    _chk(_lib().csl_sage_step_timing_read(ms, n), "csl_sage_step_timing_read")
+    return {g: (float(ms[i]), int(n[i])) for i, g in enumerate(STEP_GROUPS)}
 
 
 class SageStep(object):

@@ -291,25 +291,47 @@ class Trainer(object):
         for u in self.units:
             u["rows"] = u["src"] = u["edges"] = 0
 
+    def fused_deepest_layer(self):
+        """whether the native step runs the deepest layer as the one fused gather -> fp32-MFMA kernel"""
+        if self.native is None or os.environ.get("CSLICER_NO_MFMA_FWD"):
+            return False
+        fout, fin2 = self.model.convs[0].fc.weight.shape
+        return aggr._lib().csl_sage_fwd_mfma_scratch(fin2 // 2, fout) > 0
+
     def step_work(self, steps):
-        """Algorithmic work of one training step on this rank, from the slices actually trained (fp32):
-        GEMM flops (forward, weight gradient, input gradient except for the deepest layer) and the bytes the
-        aggregation / elementwise kernels must move (csl_sage_cat: gathered source rows + operand store; its
-        backward: operand gradient + read-modify-write of the source gradient + its zero fill; ReLU backward +
-        bias sums: gradient in, mask in, gradient out)."""
-        flops = byts = 0.0
+        """Algorithmic work of one training step on this rank (fp32), by the groups csl_sage_step_timing measures, from
+        the slices actually trained (units per model layer k: m output rows, src source rows, e edges):
+          gemm          flops of the library GEMMs: forward (k >= 1, or every layer when the deepest is not fused),
+                        weight gradient (every layer), input gradient (k >= 1), 2 m 2in out each
+          fused_forward the deepest layer as one kernel: 2 m 2in out flops; HBM bytes: (m + e) in 4 of gathered
+                        feature-table rows + m out 4 of result + m 2in 4 of operand kept for the weight gradient
+          aggregation   HBM bytes of the gather kernels, every row counted ONCE (the per-edge re-reads of a layer's
+                        sources are served by L2: the whole source matrix is a few tens of MB):
+                        forward k >= 1: src in 4 read + m 2in 4 written; backward k >= 1 (by source): m 2in 4 read
+                        + src in 4 (ReLU mask) read + src in 4 written
+        The returned dict also has the totals `gemm_flops` (fused forward included) and `aggregation_bytes`."""
+        fused = self.fused_deepest_layer()
+        w = {"gemm": {"flops": 0.0}, "fused_forward": {"flops": 0.0, "bytes": 0.0}, "aggregation": {"bytes": 0.0}}
         for k, (u, conv) in enumerate(zip(self.units, self.model.convs)):
             if not hasattr(conv, "fc"):
                 return None
             fout, fin2 = conv.fc.weight.shape
-            m, src, e = u["rows"] / steps, u["src"] / steps, u["edges"] / steps
-            flops += (2 if k == 0 else 3) * 2.0 * m * fin2 * fout
             fin = fin2 // 2
-            byts += (m + e) * fin * 4 + m * fin2 * 4                     # operand: gathers + store
-            byts += 3 * m * fout * 4                                      # ReLU backward / bias sums
+            m, src, e = u["rows"] / steps, u["src"] / steps, u["edges"] / steps
+            g = 2.0 * m * fin2 * fout
+            w["gemm"]["flops"] += g                                            # weight gradient
             if k > 0:
-                byts += m * fin2 * 4 + 2 * (m + e) * fin * 4 + src * fin * 4   # source gradient
-        return {"gemm_flops": flops, "aggregation_bytes": byts}
+                w["gemm"]["flops"] += 2 * g                                    # forward + input gradient
+                w["aggregation"]["bytes"] += (src * fin + m * fin2) * 4 + (m * fin2 + 2 * src * fin) * 4
+            elif fused:
+                w["fused_forward"]["flops"] += g
+                w["fused_forward"]["bytes"] += (m + e) * fin * 4 + m * fout * 4 + m * fin2 * 4
+            else:
+                w["gemm"]["flops"] += g
+                w["aggregation"]["bytes"] += (m + e) * fin * 4 + m * fin2 * 4
+        w["gemm_flops"] = w["gemm"]["flops"] + w["fused_forward"]["flops"]
+        w["aggregation_bytes"] = w["aggregation"]["bytes"] + w["fused_forward"]["bytes"]
+        return w
 
     def report(self):
         n = max(self.steps_done, 1)

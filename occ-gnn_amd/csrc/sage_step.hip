@@ -22,6 +22,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "cslicer_aggr.h"
 #include "cslicer_hip.h"
@@ -109,6 +111,49 @@ bool lay_out(int32_t L, const int32_t* dims, const csl_sage_slice* sl, int64_t r
   return true;
 }
 
+// ---- diagnostics: device time of the step's launches by group (csl_sage_step_timing / _read): HIP events around every
+// launch on the step's own stream, read back (and the stream drained) by the caller.  Off by default: no cost.
+struct TimedSpan {
+  int group;
+  hipEvent_t e0, e1;
+};
+bool g_timing = false;
+std::vector<TimedSpan> g_spans;       // recorded, not yet read
+std::vector<hipEvent_t> g_free;       // event pool
+std::mutex g_tmu;
+hipEvent_t take_event() {
+  if (!g_free.empty()) {
+    hipEvent_t e = g_free.back();
+    g_free.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct SpanGuard {   // records e0 now and e1 when it goes out of scope
+  hipStream_t st;
+  TimedSpan sp;
+  bool on;
+  SpanGuard(int group, void* stream) : st((hipStream_t)stream), on(g_timing) {
+    if (!on) return;
+    std::lock_guard<std::mutex> lk(g_tmu);
+    sp.group = group, sp.e0 = take_event(), sp.e1 = take_event();
+    (void)hipEventRecord(sp.e0, st);
+  }
+  ~SpanGuard() {
+    if (!on) return;
+    (void)hipEventRecord(sp.e1, st);
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_spans.push_back(sp);
+  }
+};
+#define TSTEP(group, x)              \
+  do {                               \
+    SpanGuard sg_((group), stream);  \
+    STEP(x);                         \
+  } while (0)
+
 #define STEP(x)                                                              \
   do {                                                                       \
     const int rc_ = (x);                                                     \
@@ -123,6 +168,27 @@ bool lay_out(int32_t L, const int32_t* dims, const csl_sage_slice* sl, int64_t r
 extern "C" {
 
 const char* csl_sage_last_error(void) { return s_err; }
+
+int csl_sage_step_timing(int32_t enable) {
+  std::lock_guard<std::mutex> lk(g_tmu);
+  g_timing = enable != 0;
+  return CSL_OK;
+}
+
+int csl_sage_step_timing_read(double* ms, int64_t* launches) {
+  if (!ms || !launches) return CSL_E_INVALID;
+  std::lock_guard<std::mutex> lk(g_tmu);
+  for (int g = 0; g < CSL_STEP_GROUPS; g++) ms[g] = 0.0, launches[g] = 0;
+  int rc = CSL_OK;
+  for (const TimedSpan& sp : g_spans) {
+    float t = 0.f;
+    if (hipEventSynchronize(sp.e1) != hipSuccess || hipEventElapsedTime(&t, sp.e0, sp.e1) != hipSuccess) rc = CSL_E_HIP;
+    if (sp.group >= 0 && sp.group < CSL_STEP_GROUPS) ms[sp.group] += t, launches[sp.group]++;
+    g_free.push_back(sp.e0), g_free.push_back(sp.e1);
+  }
+  g_spans.clear();
+  return rc;
+}
 
 int64_t csl_sage_fwd_bwd_workspace(int32_t n_layers, const int32_t* dims, const csl_sage_slice* slices, int64_t row_pad,
                                    int32_t n_slabs) {
@@ -166,14 +232,14 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
     if (k == 0 && o.wpack >= 0) {
       // gather [self | mean] into LDS, multiply on the fp32 matrix cores, bias + ReLU on the way out; the operand is
       // also written (the weight gradient reads it), but never read back by the forward
-      STEP(csl_sage_fwd_mfma_f32(sl[0].indptr, sl[0].indices, sl[0].self_ids_in, feat_rows, feat, ldf, weights[0],
+      TSTEP(CSL_STEP_FUSED_FWD, csl_sage_fwd_mfma_f32(sl[0].indptr, sl[0].indices, sl[0].self_ids_in, feat_rows, feat, ldf, weights[0],
                                  2 * (int64_t)in, biases[0], m, mp, in, out, 0, L > 1 ? 1 : 0, ws + o.cat[0],
                                  2 * (int64_t)in, ws + o.y[0], out, ws + o.wpack, stream));
       continue;
     }
-    STEP(csl_sage_cat_f32(sl[k].indptr, sl[k].indices, sl[k].self_ids_in, nullptr, nullptr, k == 0 ? feat_rows : nullptr, x,
+    TSTEP(CSL_STEP_AGGREGATION, csl_sage_cat_f32(sl[k].indptr, sl[k].indices, sl[k].self_ids_in, nullptr, nullptr, k == 0 ? feat_rows : nullptr, x,
                           k == 0 ? ldf : (int64_t)in, nullptr, 0, m, mp, ws + o.cat[k], 2 * (int64_t)in, in, 0, stream));
-    STEP(csl_gemm_f32(0, 1, mp, out, 2 * (int64_t)in, ws + o.cat[k], 2 * (int64_t)in, 0, weights[k], 2 * (int64_t)in, 0,
+    TSTEP(CSL_STEP_GEMM, csl_gemm_f32(0, 1, mp, out, 2 * (int64_t)in, ws + o.cat[k], 2 * (int64_t)in, 0, weights[k], 2 * (int64_t)in, 0,
                       ws + o.y[k], out, 0, 1, biases[k], k + 1 < L ? 1 : 0, stream));
   }
   // the second stages, collected: (source, blocks, width, destination)
@@ -192,13 +258,13 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
     const int32_t C = dims[L];
     const int64_t m = sl[k].n_out;
     if (o.top_cols) {
-      STEP(csl_softmax_ce_partial_f32(ws + o.y[k], C, m, o.mp[k], C, seed_ids, nullptr, labels, scale, ws + o.gy[k], C,
+      TSTEP(CSL_STEP_OTHER, csl_softmax_ce_partial_f32(ws + o.y[k], C, m, o.mp[k], C, seed_ids, nullptr, labels, scale, ws + o.gy[k], C,
                                       ws + o.lpart, ws + o.bpart[k], stream));
       defer(ws + o.bpart[k], o.bblocks[k], C, gb[k]);
     } else {
-      STEP(csl_softmax_ce_partial_f32(ws + o.y[k], C, m, m, C, seed_ids, nullptr, labels, scale, ws + o.g, C, ws + o.lpart,
+      TSTEP(CSL_STEP_OTHER, csl_softmax_ce_partial_f32(ws + o.y[k], C, m, m, C, seed_ids, nullptr, labels, scale, ws + o.g, C, ws + o.lpart,
                                       nullptr, stream));
-      STEP(csl_relu_bwd_colsum_f32(ws + o.g, C, nullptr, 0, m, o.mp[k], ws + o.gy[k], C, gb[k], ws + o.scratch, C, stream));
+      TSTEP(CSL_STEP_AGGREGATION, csl_relu_bwd_colsum_f32(ws + o.g, C, nullptr, 0, m, o.mp[k], ws + o.gy[k], C, gb[k], ws + o.scratch, C, stream));
     }
     defer(ws + o.lpart, o.top_cols ? o.lblocks : (m + 3) / 4, 1, loss);  // (blocks of four rows the loss pass covered)
   }
@@ -210,11 +276,11 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
       if (hipMemsetAsync(gW[k], 0, sizeof(float) * wn, (hipStream_t)stream) != hipSuccess) return CSL_E_HIP;
     } else if (o.slabbed[k]) {
       const int64_t rs = mp / n_slabs;
-      STEP(csl_gemm_f32(1, 0, out, 2 * (int64_t)in, rs, ws + o.gy[k], out, rs * out, ws + o.cat[k], 2 * (int64_t)in,
+      TSTEP(CSL_STEP_GEMM, csl_gemm_f32(1, 0, out, 2 * (int64_t)in, rs, ws + o.gy[k], out, rs * out, ws + o.cat[k], 2 * (int64_t)in,
                         rs * 2 * in, ws + o.slabs[k], 2 * (int64_t)in, wn, n_slabs, nullptr, 0, stream));
       defer(ws + o.slabs[k], n_slabs, (int32_t)wn, gW[k]);
     } else {
-      STEP(csl_gemm_f32(1, 0, out, 2 * (int64_t)in, mp, ws + o.gy[k], out, 0, ws + o.cat[k], 2 * (int64_t)in, 0, gW[k],
+      TSTEP(CSL_STEP_GEMM, csl_gemm_f32(1, 0, out, 2 * (int64_t)in, mp, ws + o.gy[k], out, 0, ws + o.cat[k], 2 * (int64_t)in, 0, gW[k],
                         2 * (int64_t)in, 0, 1, nullptr, 0, stream));
     }
     if (k == 0) break;
@@ -222,20 +288,20 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
       snprintf(s_err, sizeof(s_err), "layer %d has no slice by source (engine flag CSL_FLAG_TRANSPOSE)", k);
       return CSL_E_INVALID;
     }
-    STEP(csl_gemm_f32(0, 0, mp, 2 * (int64_t)in, out, ws + o.gy[k], out, 0, weights[k], 2 * (int64_t)in, 0, ws + o.gcat[k],
+    TSTEP(CSL_STEP_GEMM, csl_gemm_f32(0, 0, mp, 2 * (int64_t)in, out, ws + o.gy[k], out, 0, weights[k], 2 * (int64_t)in, 0, ws + o.gcat[k],
                       2 * (int64_t)in, 0, 1, nullptr, 0, stream));
     // gradient w.r.t. layer k-1's pre-activation output (= this layer's input x), padded like its GEMM operand;
     // its column sums (gb_{k-1}) stay as per-block partials
     if (o.hub[k]) {
       // a hub's list in the slice by source is thousands of entries, one wave's serial walk (1.3 ms instead of 30 us per
       // launch on a Zipf graph: profiles/hub_probe.py): this layer scatters with atomics, then masks / pads / sums
-      STEP(csl_sage_cat_bwd_f32(sl[k].indptr, sl[k].indices, sl[k].self_ids_in, sl[k].n_out, ws + o.gcat[k], 2 * (int64_t)in,
+      TSTEP(CSL_STEP_AGGREGATION, csl_sage_cat_bwd_f32(sl[k].indptr, sl[k].indices, sl[k].self_ids_in, sl[k].n_out, ws + o.gcat[k], 2 * (int64_t)in,
                                 ws + o.gx[k], in, sl[k].n_in, in, stream));
       if (o.mp[k - 1] > 0)
-        STEP(csl_relu_bwd_colsum_f32(ws + o.gx[k], in, ws + o.y[k - 1], in, sl[k].n_in, o.mp[k - 1], ws + o.gy[k - 1], in,
+        TSTEP(CSL_STEP_AGGREGATION, csl_relu_bwd_colsum_f32(ws + o.gx[k], in, ws + o.y[k - 1], in, sl[k].n_in, o.mp[k - 1], ws + o.gy[k - 1], in,
                                      nullptr, ws + o.bpart[k - 1], in, stream));
     } else
-    STEP(csl_sage_cat_bwd_t_f32(sl[k].t_indptr, sl[k].t_indices, sl[k].indptr, ws + o.gcat[k], 2 * (int64_t)in,
+    TSTEP(CSL_STEP_AGGREGATION, csl_sage_cat_bwd_t_f32(sl[k].t_indptr, sl[k].t_indices, sl[k].indptr, ws + o.gcat[k], 2 * (int64_t)in,
                                 ws + o.y[k - 1], in, sl[k].n_in, o.mp[k - 1], ws + o.gy[k - 1], in, nullptr,
                                 ws + o.bpart[k - 1], in, stream));
     if (o.bblocks[k - 1] > 0) defer(ws + o.bpart[k - 1], o.bblocks[k - 1], in, gb[k - 1]);
@@ -243,7 +309,7 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
   }
   // ---- every deferred second stage (bias sums, weight-gradient slabs, the loss) in one launch
   k = -1;
-  STEP(csl_reduce_multi_f32(nr, r_src, r_nblk, r_h, r_dst, stream));
+  TSTEP(CSL_STEP_OTHER, csl_reduce_multi_f32(nr, r_src, r_nblk, r_h, r_dst, stream));
   return CSL_OK;
 }
 

@@ -1,0 +1,106 @@
+"""The TIMED native training step (csl_sage_fwd_bwd_f32: what bench.py's e2e leg and the trainer run) at the bench's
+widths, against a dense float64 computation on the ORACLE's traversal -- not against another HIP path.
+
+Model: python/models/factory.py:7-56 (3 x SAGEConv: Linear(2*in, out) over [self | mean of the sampled neighbours], ReLU
+between), loss python/train.py:86 (cross-entropy, mean over the minibatch).  Shape: features 100, hidden 256, 47 classes,
+fanout 15/10/5 (layer 0 = the seeds' hop), minibatch 1024 on a 400 k-node products-like graph, rows padded to the
+trainer's ROW_PAD, weight gradients in the trainer's row slabs, hipBLASLt plans as the trainer records them, the
+deepest layer through the fused gather -> fp32-MFMA kernel (and, second case, through csl_sage_cat_f32 + library GEMM).
+
+The reference ships no fixture for this ("parity unpinned" by the reference): the expected values are computed here in
+float64 from the CPU oracle's sampled neighbourhoods (nbr_flat / nbr_counts of the pinned restatement), so a slicing
+error, an aggregation error and a GEMM error would all show.  Tolerances (north_star): loss 1e-5 relative, every
+parameter gradient within 1e-4 of its largest entry.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _float64_reference(trav, feats, labels, weights, biases, n_nodes):
+    """loss and parameter gradients (float64, CPU autograd) of the model on the oracle's traversal"""
+    L = len(trav["nbr_counts"])
+    ws = [w.detach().double().cpu().requires_grad_() for w in weights]
+    bs = [b.detach().double().cpu().requires_grad_() for b in biases]
+    src_nodes = np.asarray(trav["frontier"][L], dtype=np.int64)           # every node the deepest hop reads
+    h = torch.from_numpy(np.asarray(feats)[src_nodes]).double()
+    for k in range(L):
+        l = L - 1 - k
+        fr = np.asarray(trav["frontier"][l], dtype=np.int64)
+        counts = np.asarray(trav["nbr_counts"][l], dtype=np.int64)
+        flat = np.asarray(trav["nbr_flat"][l], dtype=np.int64)
+        lut = np.full(n_nodes, -1, dtype=np.int64)
+        lut[src_nodes] = np.arange(src_nodes.shape[0])
+        starts = np.zeros(fr.shape[0] + 1, dtype=np.int64)
+        np.cumsum(counts, out=starts[1:])
+        assert np.array_equal(flat[starts[:-1]], fr)                       # every list starts with the node itself
+        keep = np.ones(flat.shape[0], dtype=bool)
+        keep[starts[:-1]] = False
+        row = np.repeat(np.arange(fr.shape[0]), counts)
+        keep &= flat != fr[row]                                            # (a sampled self loop is not a neighbour)
+        row, nb = row[keep], flat[keep]
+        assert (lut[nb] >= 0).all() and (lut[fr] >= 0).all()
+        agg = torch.zeros(fr.shape[0], h.shape[1], dtype=torch.float64)
+        agg.index_add_(0, torch.from_numpy(row), h[torch.from_numpy(lut[nb])])
+        deg = torch.from_numpy(np.bincount(row, minlength=fr.shape[0])).double().clamp(min=1)
+        cat = torch.cat([h[torch.from_numpy(lut[fr])], agg / deg.unsqueeze(1)], 1)
+        h = cat @ ws[k].t() + bs[k]
+        if k + 1 < L:
+            h = torch.relu(h)
+        src_nodes = fr
+    seeds = np.asarray(trav["frontier"][0], dtype=np.int64)
+    y = torch.from_numpy(np.asarray(labels)[seeds])
+    loss = torch.nn.functional.cross_entropy(h, y, reduction="sum") / seeds.shape[0]
+    loss.backward()
+    grads = []
+    for w, b in zip(ws, bs):
+        grads += [w.grad, b.grad]
+    return float(loss), grads
+
+
+@pytest.mark.parametrize("fused_deepest_layer", [True, False])
+def test_native_step_at_the_bench_widths_matches_float64_on_the_oracle_traversal(fused_deepest_layer, monkeypatch):
+    from cslicer import _abi, aggr, l0, splitgnn
+    from cslicer.train import synthetic_node_data
+    from oracle import oracle as orc
+    _abi.load()
+    if not fused_deepest_layer:
+        monkeypatch.setenv("CSLICER_NO_MFMA_FWD", "1")
+    n, F0, hidden, classes, B, fan = 400_000, 100, 256, 47, 1024, (15, 10, 5)
+    indptr, indices = l0.synth_graph(n, 50.5, seed=0)
+    feats, labels = synthetic_node_data(n, F0, classes, seed=0)
+    seeds = np.random.default_rng(1).permutation(n)[:B]
+    torch.manual_seed(0)
+    model = splitgnn.DistSAGEModel(F0, hidden, classes, n_layers=3).cuda()
+    ws, bs = [c.fc.weight for c in model.convs], [c.fc.bias for c in model.convs]
+
+    # ---- the HIP path: slicer (graph mode + slices by source) -> csl_sage_fwd_bwd_f32
+    eng = _abi.Engine(indptr, indices, n_parts=1, fanouts=fan, max_batch=B, mode=_abi.MODE_GRAPH, flags=_abi.FLAG_TRANSPOSE)
+    eng.submit_seeds([seeds])
+    slices = splitgnn.slices_of(eng)
+    step = aggr.SageStep(model, splitgnn.ROW_PAD, splitgnn.SPLIT_K)
+    got_loss = torch.zeros(1, device="cuda")
+    x = torch.from_numpy(feats).cuda()
+    lab = torch.from_numpy(labels).cuda()
+    for _ in range(2):   # (the second call runs on the recorded GEMM plans and the reused workspace)
+        step([slices[2][0], slices[1][0], slices[0][0]], x, lab, 1.0 / B, got_loss)
+    torch.cuda.synchronize()
+    got = step.grads.double().cpu()
+
+    # ---- float64 on the oracle's traversal of the same seeds
+    trav = orc.Oracle(indptr, indices, n_parts=1, fanouts=fan).sample(seeds)
+    assert int(slices[0][0].n_out) == B and int(slices[2][0].n_in) == len(trav["frontier"][3])
+    want_loss, want = _float64_reference(trav, feats, labels, ws, bs, n)
+
+    assert abs(float(got_loss[0]) - want_loss) <= 1e-5 * abs(want_loss), (float(got_loss[0]), want_loss)
+    at = 0
+    for k, g in enumerate(want):
+        seg = got[at:at + g.numel()].reshape(g.shape)
+        at += g.numel()
+        err, ref = float((seg - g).abs().max()), float(g.abs().max())
+        assert err <= 1e-4 * ref, "gradient %d (%s of layer %d): max error %.3g against a largest entry of %.3g" % (
+            k, "weight" if k % 2 == 0 else "bias", k // 2, err, ref)
+    assert at == got.numel()
+    eng.close()
