@@ -180,9 +180,10 @@ int csl_softmax_ce_partial_f32(const float* logits, int64_t ldl, int64_t n, int6
                                const int32_t* rowmap, const int64_t* labels, float scale, float* grad, int64_t ldgr,
                                float* loss_partial, float* col_partial, void* stream);
 
-/* dst[j][c] = sum over b < nblk[j] of src[j][b * H[j] + c], c < H[j], for count <= 12 jobs in ONE launch: the second
+/* dst[j][c] = sum over b < nblk[j] of src[j][b * H[j] + c], c < H[j], for count <= CSL_REDUCE_MULTI_MAX (12) jobs in ONE launch: the second
  * stage of a step's two-stage reductions (column sums, the loss with H = 1, the row slabs of a weight gradient).
  * src / nblk / H / dst are HOST arrays. */
+#define CSL_REDUCE_MULTI_MAX 12
 int csl_reduce_multi_f32(int32_t count, const float* const* src, const int64_t* nblk, const int32_t* H, float* const* dst,
                          void* stream);
 
@@ -200,7 +201,11 @@ int csl_adam_f32(int32_t count, float* const* params, const float* const* grads,
  * is chosen by timing the library's candidates on its first use (C is overwritten several times then; environment
  * CSLICER_GEMM_TUNE=0 takes the library's first suggestion, CSLICER_GEMM_LOG=1 reports each choice).  The library
  * is bound at run time (the libhipblaslt.so.1 already in the process, else ROCm's).  csl_gemm_last_error: details
- * of the last failure. */
+ * of the last failure.
+ * ONE device and ONE stream per process: the library handle and the 128 MB workspace every plan shares are created by
+ * the first call, on its device, for its stream; a call from another device or stream returns CSL_E_STATE (two GEMMs
+ * on different streams would use the same workspace).  The trainer's contract: one GPU per process, one training
+ * stream. */
 int csl_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k, const float* A, int64_t lda,
                  int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b, float* C, int64_t ldc, int64_t stride_c,
                  int32_t batch, const float* bias, int32_t relu, void* stream);

@@ -152,14 +152,35 @@ def _check(rc):
     return rc
 
 
+ERR_FRONTIER_CAP = 8
+E_DEVICE = -5    # CSL_E_DEVICE: the device flagged an error in a sample (csl_sample_meta.error)
+
+
 class Engine:
-    """Owns one csl_engine. Thin, argument-for-argument wrapper of the C ABI."""
+    """Owns one csl_engine. Thin, argument-for-argument wrapper of the C ABI.
+
+    Recovery from CSL_ERR_FRONTIER_CAP (the reference's vectors simply grow, bipartite.h:55-66; here a frontier that
+    outgrows a USER-given `frontier_cap` poisons the sample, loudly): with `frontier_cap` given and `recover=True`
+    (default) the wrapper keeps every submission since creation; the first sample that reports the overflow makes it
+    build a FRESH engine with the worst-case capacities (never a re-exec, nothing shared with the old one) and replay
+    the submissions, so that every stream's mt19937 position -- and with it every later sample -- is what an engine
+    created with enough room would have produced.  `self.recovered` counts how often that happened (at most once: the
+    worst case cannot overflow)."""
 
     def __init__(self, indptr, indices, n_parts=4, fanouts=(10, 10, 10), max_batch=1024,
                  n_streams=1, n_slots=1, workload=None, device=0, rng_seed=5489,
-                 rng_ring_log2=0, frontier_cap=None, mode=MODE_STRICT, flags=0, part_mask=0):
-        L = load()
+                 rng_ring_log2=0, frontier_cap=None, mode=MODE_STRICT, flags=0, part_mask=0, recover=True):
         self._h = None
+        self._kw = dict(n_parts=n_parts, fanouts=fanouts, max_batch=max_batch, n_streams=n_streams, n_slots=n_slots,
+                        workload=workload, device=device, rng_seed=rng_seed, rng_ring_log2=rng_ring_log2, mode=mode,
+                        flags=flags, part_mask=part_mask)
+        self._log = [] if (frontier_cap is not None and recover) else None   # submissions since creation
+        self.recovered = 0
+        self._create(indptr, indices, frontier_cap=frontier_cap, **self._kw)
+
+    def _create(self, indptr, indices, n_parts, fanouts, max_batch, n_streams, n_slots, workload, device, rng_seed,
+                rng_ring_log2, frontier_cap, mode, flags, part_mask):
+        L = load()
         self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
         self.indices = np.ascontiguousarray(indices, dtype=np.int64)
         self.workload = None if workload is None else np.ascontiguousarray(workload, dtype=np.int32)
@@ -211,16 +232,33 @@ class Engine:
         except Exception:
             pass
 
+    def _recover(self, err):
+        """a sample overflowed a user-given frontier capacity: fresh engine, worst-case capacities, same history"""
+        if self._log is None:
+            raise err
+        log, self._log = self._log, None          # (the replay below must not log again; the worst case cannot overflow)
+        self.close()
+        self._create(self.indptr, self.indices, frontier_cap=None, **self._kw)
+        for what, args in log:
+            getattr(self, what)(*args)
+        self.recovered += 1
+
     # -- submission
     def set_nodes(self, nodes):
         nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        if self._log is not None:
+            self._log.append(("set_nodes", (nodes.copy(),)))   # (callers shuffle their node order in place)
         _check(load().csl_set_nodes(self._h, nodes.ctypes.data_as(C.POINTER(C.c_int64)), nodes.shape[0]))
 
     def submit_round(self, first_batch, batch_size, n_batches=None, slot=0):
         n_batches = self.n_streams if n_batches is None else n_batches
+        if self._log is not None:
+            self._log.append(("submit_round", (first_batch, batch_size, n_batches, slot)))
         _check(load().csl_submit_round(self._h, first_batch, batch_size, n_batches, slot))
 
     def submit_seeds(self, batches, slot=0):
+        if self._log is not None:
+            self._log.append(("submit_seeds", ([np.array(b, dtype=np.int64) for b in batches], slot)))
         flat = np.ascontiguousarray(
             np.concatenate([np.asarray(b, dtype=np.int64).reshape(-1) for b in batches])
             if len(batches) else np.zeros(0, dtype=np.int64))
@@ -237,7 +275,14 @@ class Engine:
     # -- results
     def meta(self, stream=0, slot=0):
         m = SampleMeta()
-        _check(load().csl_get_meta(self._h, slot, stream, C.byref(m)))
+        try:
+            _check(load().csl_get_meta(self._h, slot, stream, C.byref(m)))
+        except CslError as err:
+            if err.code != E_DEVICE or not (int(m.error) & ERR_FRONTIER_CAP) or self._log is None:
+                raise
+            self._recover(err)
+            m = SampleMeta()
+            _check(load().csl_get_meta(self._h, slot, stream, C.byref(m)))
         return m
 
     def copy_list(self, layer, kind, part, stream=0, slot=0, meta=None):

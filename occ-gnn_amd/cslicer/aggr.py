@@ -482,6 +482,16 @@ class SageRankStep(object):
             s = self._cur[layer]
             send, recv = (s.to_counts, s.from_counts) if backward else (s.from_counts, s.to_counts)
             out, inp = self._view(dst, sum(recv), width), self._view(src, sum(send), width)
+            # (a first real multi-GPU run must fail loudly rather than exchange misaligned rows: the per-peer counts
+            # come from the sample's pair offsets, the list lengths from its list offsets, the peers from the group)
+            n_from, n_to = s.count(_abi.FROM_IDS), s.count(_abi.TO_IDS)
+            n_send, n_recv = (n_to, n_from) if backward else (n_from, n_to)
+            world = getattr(self.comm, "world", len(send))
+            if (sum(send) != n_send or sum(recv) != n_recv or len(send) != world or len(recv) != world
+                    or min(list(send) + list(recv) + [0]) < 0 or send[s.part] != 0 or recv[s.part] != 0):
+                raise RuntimeError("layer %d %s exchange of part %d: per-peer counts %r / %r against boundary lists of %d "
+                                   "and %d rows, %d peers" % (layer, "backward" if backward else "forward", s.part,
+                                                              list(send), list(recv), n_send, n_recv, world))
             if not self.overlap:
                 self.comm.exchange_into(out, inp, send, recv)
                 return 0

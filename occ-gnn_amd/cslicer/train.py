@@ -30,7 +30,7 @@ class Trainer(object):
 
     def __init__(self, indptr, indices, features, labels, n_classes, rank=0, world=1, fanouts=(15, 10, 5),
                  batch=1024, streams=8, hidden=256, lr=1e-3, device=0, dist=None, seed=0, overlap=False,
-                 model="sage", heads=8, rank_path=None, workload=None, feat_dim=None):
+                 model="sage", heads=8, rank_path=None, workload=None, feat_dim=None, rng_seed=5489):
         """Part `rank` of `world`.  Ownership = the engine's workload table (`workload` int32 [N], the METIS map of
         python/utils/sampler.py:64-134 / partition_map_opt.bin; None = v % world like pyfrontend.cpp:57): the rank
         keeps the feature and label rows of the nodes it owns, in ascending node order.
@@ -64,7 +64,7 @@ class Trainer(object):
         self.eng = _abi.Engine(indptr, indices, n_parts=self.P, fanouts=fanouts, max_batch=batch,
                                n_streams=streams, n_slots=self.SLOTS, device=device, mode=_abi.MODE_GRAPH,
                                workload=workload, part_mask=(1 << rank) if self.rank_path else 0,
-                               flags=eng_flags)
+                               flags=eng_flags, rng_seed=rng_seed)
         if workload is None:
             own = np.arange(rank, N, self.P, dtype=np.int64)           # owner v % P holds v at local row v // P
         else:
@@ -355,6 +355,10 @@ class DataParallelTrainer(Trainer):
     def __init__(self, indptr, indices, features, labels, n_classes, dp_rank, dp_world, dist, batch=1024, **kw):
         self.dp_rank, self.dp_world, self.dp_dist, self.global_B = int(dp_rank), int(dp_world), dist, int(batch)
         self.chunk = (self.global_B + self.dp_world - 1) // self.dp_world
+        # every rank samples its OWN chunk of a minibatch: the ranks' mt19937 streams must differ, or rank r and rank r'
+        # consume the same draws for their chunks and the sampling noise of the reduced gradient does not average out as
+        # 1 / W (the split-parallel trainer is the opposite case: every rank must slice the SAME minibatch, same seed)
+        kw.setdefault("rng_seed", 5489 + 7919 * self.dp_rank)
         super().__init__(indptr, indices, features, labels, n_classes, rank=0, world=1, batch=self.chunk, dist=None,
                          rank_path=False, **kw)
         if self.native is None:

@@ -714,7 +714,7 @@ __global__ __launch_bounds__(BLK) void k_softmax_ce(const float* __restrict__ lo
 // dst_j[c] = sum over b < nblk_j of src_j[b * H_j + c] for up to RM_MAX jobs in ONE launch: the second stage of every
 // two-stage reduction of a training step (bias column sums, the loss, the row slabs of the weight gradients) when the
 // results are only needed at the step's end -- one launch instead of one 5-9 us launch each.
-constexpr int RM_MAX = 12;
+constexpr int RM_MAX = CSL_REDUCE_MULTI_MAX;
 struct ReduceJobs {
   const float* src[RM_MAX];
   float* dst[RM_MAX];

@@ -77,6 +77,8 @@ struct State {
   hipblasLtHandle_t handle = nullptr;
   void* ws = nullptr;
   size_t ws_bytes = 0;
+  int device = -1;            // the device the handle and the workspace were created on
+  void* stream = nullptr;     // the ONE stream GEMMs are issued on (the workspace is shared by every plan)
   std::map<Key, Plan> plans;
   // the algorithm last chosen for a shape CLASS (the shape with its long dimension -- the rows of a minibatch layer:
   // m, or k of a weight gradient -- blanked): a new row count of a known class takes it without timing anything
@@ -275,6 +277,14 @@ int make_plan_impl(const Key& key, Plan& p, const float* A, const float* B, floa
   int best = -1;
   float best_us = 0.f;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct EvGuard {   // the tuning loop has early error returns: the events go with the scope
+    hipEvent_t &a, &b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+      a = b = nullptr;
+    }
+  } ev_guard{e0, e1};
   if (tune) {
     HIPOK(hipEventCreate(&e0));
     HIPOK(hipEventCreate(&e1));
@@ -311,10 +321,6 @@ int make_plan_impl(const Key& key, Plan& p, const float* A, const float* B, floa
       best = i;
       best_us = us;
     }
-  }
-  if (tune) {
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
   }
   if (best < 0) {
     snprintf(g.err, sizeof(g.err), "none of hipBLASLt's %d candidates ran for this GEMM", got);
@@ -373,10 +379,23 @@ int csl_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k
   if (lda < (transa ? m : k) || ldb < (transb ? k : n) || ldc < n) return CSL_E_INVALID;
   std::lock_guard<std::mutex> lock(g.mu);
   if (!load_api()) return CSL_E_HIP;
-  if (!g.handle) {
-    LT(g.api.Create(&g.handle));
-    HIPOK(hipMalloc(&g.ws, WS_BYTES));
-    g.ws_bytes = WS_BYTES;
+  {
+    // one handle and one workspace per process: every GEMM must come from the device they were created on and from
+    // ONE stream (two GEMMs on different streams would share the workspace; a second device would get the first one's
+    // memory).  The trainer's contract (one GPU per process, one training stream); anything else is refused, loudly.
+    int dev = -1;
+    HIPOK(hipGetDevice(&dev));
+    if (!g.handle) {
+      LT(g.api.Create(&g.handle));
+      HIPOK(hipMalloc(&g.ws, WS_BYTES));
+      g.ws_bytes = WS_BYTES;
+      g.device = dev;
+      g.stream = stream;
+    } else if (dev != g.device || stream != g.stream) {
+      snprintf(g.err, sizeof(g.err), "csl_gemm_f32 is bound to device %d and the stream of its first call (one workspace): "
+               "called from device %d / another stream", g.device, dev);
+      return CSL_E_STATE;
+    }
   }
   const int epi = bias ? (relu ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS)
                        : (relu ? HIPBLASLT_EPILOGUE_RELU : HIPBLASLT_EPILOGUE_DEFAULT);

@@ -56,6 +56,7 @@ constexpr unsigned OOB = 0xF0000000u;   // beyond every buffer this path accepts
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, SRD_FLAGS);
 }
+constexpr int ZROW4 = 80;                   // float4 of the zero row (320 floats: in <= 298 is all that fits the LDS)
 constexpr int NCONS = 4;                    // consumer (MFMA) waves: one per SIMD
 constexpr int NPROD = 4;                    // producer (gather / store) waves: one per SIMD
 constexpr int TBP = 64 * (NCONS + NPROD);   // 512 threads: two waves per SIMD, 256 registers each
@@ -64,7 +65,19 @@ constexpr int BM = 32;                      // rows of a tile: one MFMA m-tile
 constexpr int EC = 6;                       // edges of a row whose feature rows are requested together
 constexpr int NR = 4;                       // rows a group of 32 producer lanes gathers at once (BM / (PT / 32))
 constexpr int EMAX = 16;                    // resolved neighbour rows staged per output row (longer rows: generic path)
-constexpr int IDXW = EMAX + 2;              // [degree, self row, neighbour rows]
+constexpr int IDXW = 3 * EC + 2;            // staged per output row: [degree, address of the self row, of the neighbour rows]:
+                                            // every slot the fast path's three edge passes can load, so that the slots beyond
+                                            // EMAX hold the zero row's address too (they are loaded from unconditionally)
+static_assert(3 * EC >= EMAX, "the staged row covers every slot a fast-path pass loads");
+typedef unsigned long long StagedT;          // (64-bit: an address, the row of zeros where there is nothing to fetch)
+// (an address that went through LDS as an integer is loaded from as GLOBAL memory, said explicitly: a generic pointer
+// would make it a flat load, which counts in both wait counters and completes out of order)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* GlobalF4;
+__device__ __forceinline__ float4 ldg4(StagedT addr) {
+  const f32x4 v = *reinterpret_cast<GlobalF4>((uintptr_t)addr);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 constexpr int NSL = EMAX * BM / PT;         // edge slots of a row per producer thread in the index pipeline (2)
 
 struct FwdArgs {
@@ -75,7 +88,7 @@ struct FwdArgs {
   const float* x;
   long long ldx;
   const float4* wp;   // packed W: [K2/8][NTp][64 lanes] float4
-  const float* zero;  // 128 zero floats behind it: what a lane with nothing to fetch loads
+  const float* zero;  // a row of zeros behind it (as wide as the widest accepted layer): what a lane with nothing to fetch loads
   const float* bias;
   float* cat;         // optional [n_pad][ldc]
   long long ldc;
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(256) void k_pack_w(const float* __restrict__ W, lon
                                                 float4* __restrict__ wp) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long long)KQ * NTp * 64) {
-    if (i < (long long)KQ * NTp * 64 + 32) wp[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero row behind the packed W
+    if (i < (long long)KQ * NTp * 64 + ZROW4) wp[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero row behind the packed W
     return;
   }
   const int lane = (int)(i & 63);
@@ -146,14 +159,26 @@ __device__ __forceinline__ void pipe_issue(const FwdArgs& a, int t, int S, int b
   const long long rc = pl.okP ? rP : 0;
   pl.m_e0 = a.indptr_ld[rc], pl.m_e1 = a.indptr_ld[rc + 1], pl.m_sid = a.self_ld[rc];
 }
-__device__ __forceinline__ void pipe_finish(const FwdArgs& a, int t, int S, int j, int* Ibuf, ProdState& st,
+// The staged entries are ADDRESSES of the feature-table rows (of the zero row where there is none), computed here once per
+// (row, slot): each of the 32 lanes that later fetch a row adds its column and loads -- one vector instruction per load
+// instead of a 64-bit multiply-add and a select in every lane (the fp32 MFMA and the vector ALU share the SIMD's fp32
+// lanes on this chip: every vector instruction a producer issues is taken from the consumer beside it).
+__device__ __forceinline__ void pipe_finish(const FwdArgs& a, int t, int S, int j, StagedT* Ibuf, ProdState& st,
                                             const PipeLoads& pl) {
   const int pr = j >> 3, ps = j & 7;
   if (t + 2 >= 0 && t + 2 < S) {
-    int* Iw = Ibuf + ((t + 6) % 3) * BM * IDXW + pr * IDXW;   // tile t+2's (tile T lives in slot (T + 4) % 3)
+    StagedT* Iw = Ibuf + ((t + 6) % 3) * BM * IDXW + pr * IDXW;   // tile t+2's (tile T lives in slot (T + 4) % 3)
+    const StagedT zero = (StagedT)(uintptr_t)a.zero;
 #pragma unroll
-    for (int k = 0; k < NSL; k++) Iw[2 + ps + 8 * k] = st.i_raw[k] >= 0 ? (a.rowmap ? pl.m_nbr[k] : st.i_raw[k]) : -1;
-    if (ps == 0) Iw[0] = st.i_deg, Iw[1] = st.i_sid >= 0 ? (a.rowmap ? pl.m_self : st.i_sid) : -1;
+    for (int k = 0; k < NSL; k++) {
+      const long long row = a.rowmap ? pl.m_nbr[k] : st.i_raw[k];
+      Iw[2 + ps + 8 * k] = st.i_raw[k] >= 0 ? (StagedT)(uintptr_t)(a.x + row * a.ldx) : zero;
+    }
+    if (ps == 0) {
+      const long long row = a.rowmap ? pl.m_self : st.i_sid;
+      Iw[0] = (StagedT)(unsigned)st.i_deg;
+      Iw[1] = st.i_sid >= 0 ? (StagedT)(uintptr_t)(a.x + row * a.ldx) : zero;
+    }
   }
 #pragma unroll
   for (int k = 0; k < NSL; k++) st.i_raw[k] = (a.indices && ps + 8 * k < st.p_deg) ? pl.m_raw[k] : -1;
@@ -168,41 +193,32 @@ __device__ __forceinline__ void pipe_finish(const FwdArgs& a, int t, int S, int 
 // operation in it between the issue and the use of a load: the compiler then waits with counted vmcnt instead of
 // draining the queue.
 template <int EP>
-__device__ __forceinline__ void chunk_issue(const FwdArgs& a, const int* I_tile, int g, int cl, int k, float4 (&r)[2 * (EC + 1)]) {
-  // every load is issued: a lane with nothing to fetch (no self row, a shorter row, a column beyond the width) reads a
-  // row of zeros.  No branch around a load (a join the compiler's wait insertion does not count across), and no select
-  // afterwards: on this chip the fp32 MFMA and the vector ALU share the fp32 lanes, so every vector instruction of a
-  // producer is taken from the consumer on the same SIMD.
+__device__ __forceinline__ void chunk_issue(const StagedT* I_tile, int g, unsigned cb, int k, float4 (&r)[2 * (EC + 1)]) {
+  // every load is issued: a slot with nothing to fetch (no self row, a shorter row) holds the address of a row of zeros.
+  // No branch around a load (a join the compiler's wait insertion does not count across), no select afterwards.
   const int P = k / EP, p = k % EP;
 #pragma unroll
   for (int w = 0; w < 2; w++) {
-    const int* I = I_tile + (g + 16 * P + 8 * w) * IDXW;
-    const int deg = I[0], sr = I[1];
+    const StagedT* I = I_tile + (g + 16 * P + 8 * w) * IDXW;
     float4* rr = r + w * (EC + 1);
-    if (p == 0) {
-      const float* src = (sr >= 0 && cl >= 0) ? a.x + (long long)sr * a.ldx + cl : a.zero;
-      rr[0] = *reinterpret_cast<const float4*>(src);
-    }
+    if (p == 0) rr[0] = ldg4(I[1] + cb);
 #pragma unroll
-    for (int e = 0; e < EC; e++) {
-      const float* src = (EC * p + e < deg && cl >= 0) ? a.x + (long long)I[2 + EC * p + e] * a.ldx + cl : a.zero;
-      rr[1 + e] = *reinterpret_cast<const float4*>(src);
-    }
+    for (int e = 0; e < EC; e++) rr[1 + e] = ldg4(I[2 + EC * p + e] + cb);
   }
 }
 
 template <int EP, bool RELU>
 __device__ __forceinline__ void producer_step_fast(const FwdArgs& a, int t, int S, int b, int G, int j, float* Abuf,
-                                                   int* Ibuf, ProdState& st) {
+                                                   StagedT* Ibuf, ProdState& st) {
   const int H = a.H, lda = a.lda;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   PipeLoads pl;
   pipe_issue(a, t, S, b, G, j, st, pl);
   const bool doF = t >= 0 && t < S, doN = t + 1 >= 0 && t + 1 < S;
   const int g = j >> 5, gl = j & 31, c = gl * 4;
-  const int cl = c < H ? c : -1;                        // (lanes beyond the row's width fetch zeros)
-  const int* Ib = Ibuf + ((t + 4) % 3) * BM * IDXW;    // tile t's staged rows (initial values before tile 0's are there)
-  const int* In = doN ? Ibuf + ((t + 5) % 3) * BM * IDXW : Ib;    // tile t+1's (the last step loads the last tile again)
+  const unsigned cb = c < H ? (unsigned)c * 4u : 0u;    // (lanes beyond the row's width fetch its first quad again: same line)
+  const StagedT* Ib = Ibuf + ((t + 4) % 3) * BM * IDXW;    // tile t's staged rows (initial values before tile 0's are there)
+  const StagedT* In = doN ? Ibuf + ((t + 5) % 3) * BM * IDXW : Ib;    // tile t+1's (the last step loads the last tile again)
   float* A = Abuf + (t & 1) * BM * lda;
   float4 m[2];
   m[0] = m[1] = z4;
@@ -222,7 +238,7 @@ __device__ __forceinline__ void producer_step_fast(const FwdArgs& a, int t, int 
 #pragma unroll
       for (int e = 0; e < EC; e++) acc4(m[w], RELU ? relu4(rr[1 + e], 0.f) : rr[1 + e]);
       if (p == EP - 1) {
-        const int deg = Ib[rl * IDXW];
+        const int deg = (int)Ib[rl * IDXW];
         const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
         float4 mm = m[w];
         mm.x *= inv, mm.y *= inv, mm.z *= inv, mm.w *= inv;
@@ -230,15 +246,15 @@ __device__ __forceinline__ void producer_step_fast(const FwdArgs& a, int t, int 
       }
     }
     // the set takes the chunk after the next: of this tile, or of the next one
-    if (k + 2 < 2 * EP) chunk_issue<EP>(a, Ib, g, cl, k + 2, r);
-    else chunk_issue<EP>(a, In, g, cl, k + 2 - 2 * EP, r);
+    if (k + 2 < 2 * EP) chunk_issue<EP>(Ib, g, cb, k + 2, r);
+    else chunk_issue<EP>(In, g, cb, k + 2 - 2 * EP, r);
   }
   pipe_finish(a, t, S, j, Ibuf, st, pl);
 }
 
 // ---- the generic path (rows of any length, any width): stage F of tile t is issued and waited for inside step t
 __device__ __forceinline__ void producer_step_slow(const FwdArgs& a, int t, int S, int b, int G, int j, float* Abuf,
-                                                   int* Ibuf, ProdState& st) {
+                                                   StagedT* Ibuf, ProdState& st) {
   const int H = a.H, lda = a.lda;
   const float lo = a.relu_in ? 0.f : -__builtin_inff();
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -246,27 +262,28 @@ __device__ __forceinline__ void producer_step_slow(const FwdArgs& a, int t, int 
   pipe_issue(a, t, S, b, G, j, st, pl);
   if (t >= 0 && t < S) {
     const int g = j >> 5, gl = j & 31;
-    const int* Ib = Ibuf + ((t + 4) % 3) * BM * IDXW;
+    const StagedT* Ib = Ibuf + ((t + 4) % 3) * BM * IDXW;
     const long long row0 = (long long)(b + (long long)t * G) * BM;
     float* A = Abuf + (t & 1) * BM * lda;
     for (int c = gl * 4; c < H; c += 128) {
 #pragma unroll
       for (int u = 0; u < NR; u++) {
         const int rl = g + 8 * u;
-        const int* I = Ib + rl * IDXW;
-        const int deg = I[0], sr = I[1];
+        const StagedT* I = Ib + rl * IDXW;
+        const int deg = (int)I[0];
         float4 s4 = z4, m = z4;
         if (!(a.dbg & 1)) {
-          if (sr >= 0) s4 = relu4(*reinterpret_cast<const float4*>(a.x + (long long)sr * a.ldx + c), lo);
+          s4 = relu4(ldg4(I[1] + 4u * (unsigned)c), lo);   // (the zero row stays zero)
           for (int e = 0; e < deg; e++) {
-            long long s;
+            StagedT src;
             if (e < EMAX) {
-              s = I[2 + e];
+              src = I[2 + e];
             } else {
-              s = a.indices[(long long)a.indptr[row0 + rl] + e];
+              long long s = a.indices[(long long)a.indptr[row0 + rl] + e];
               if (a.rowmap) s = a.rowmap[s];
+              src = (StagedT)(uintptr_t)(a.x + s * a.ldx);
             }
-            acc4(m, relu4(*reinterpret_cast<const float4*>(a.x + s * a.ldx + c), lo));
+            acc4(m, relu4(ldg4(src + 4u * (unsigned)c), lo));
           }
         }
         const float inv = 1.0f / (float)(deg > 1 ? deg : 1);
@@ -280,7 +297,7 @@ __device__ __forceinline__ void producer_step_slow(const FwdArgs& a, int t, int 
 }
 
 template <int MODE, bool RELU>   // 1, 2, 3: fast path with that many edge passes; 0: generic
-__device__ __forceinline__ void producer_loop(const FwdArgs& a, int S, int b, int G, int j, float* Abuf, int* Ibuf,
+__device__ __forceinline__ void producer_loop(const FwdArgs& a, int S, int b, int G, int j, float* Abuf, StagedT* Ibuf,
                                               ProdState& st) {
   // (no global store anywhere in a producer, diagnostics included: with stores and loads both pending in the queue the
   // compiler stops counting and waits with vmcnt(0), which would drain the next tile's loads at every use of this one's)
@@ -456,8 +473,8 @@ template <int KS, int KL, bool STREAM>
 __global__ __launch_bounds__(TBP) void k_sage_fwd_mfma(const FwdArgs a) {
   extern __shared__ float4 smem4[];
   float* Abuf = reinterpret_cast<float*>(smem4);               // [2][BM][lda]
-  int* Ibuf = reinterpret_cast<int*>(Abuf + 2 * BM * a.lda);   // [3][BM][IDXW]
-  float4* Wl = reinterpret_cast<float4*>(Ibuf + 4 * BM * IDXW);   // [KL][NCONS][2][64]  (16-byte aligned: 4 x 32 x 18 ints)
+  StagedT* Ibuf = reinterpret_cast<StagedT*>(Abuf + 2 * BM * a.lda);   // [3][BM][IDXW]
+  float4* Wl = reinterpret_cast<float4*>(Ibuf + 4 * BM * IDXW);   // [KL][NCONS][2][64]  (16-byte aligned)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int G = gridDim.x, b = blockIdx.x;
   const int S = (a.n_tiles - b + G - 1) / G;   // this workgroup's tiles: b, b + G, ...
@@ -474,7 +491,7 @@ __global__ __launch_bounds__(TBP) void k_sage_fwd_mfma(const FwdArgs a) {
     }
     if (md > 0) atomicMax(&s_maxdeg, md);
     // staged rows start as "no self row, no edges" (the prologue steps read them)
-    for (int i = j; i < 3 * BM * IDXW; i += PT) Ibuf[i] = (i % IDXW) == 0 ? 0 : -1;
+    for (int i = j; i < 3 * BM * IDXW; i += PT) Ibuf[i] = (i % IDXW) == 0 ? (StagedT)0 : (StagedT)(uintptr_t)a.zero;
   }
   __syncthreads();
   if (wave >= NCONS) {
@@ -540,7 +557,7 @@ __global__ __launch_bounds__(TBP) void k_sage_fwd_mfma(const FwdArgs a) {
 inline int lda_for(int H) { return 2 * H + 4; }  // 2 H is a multiple of 8, so (2 H + 4) / 4 is odd
 inline int ntp_for(int out) { return ((out + 31) / 32 + 1) & ~1; }
 inline size_t lds_for(int H, int out, int KL) {
-  return (size_t)2 * BM * lda_for(H) * sizeof(float) + (size_t)4 * BM * IDXW * sizeof(int) + 64 +
+  return (size_t)2 * BM * lda_for(H) * sizeof(float) + (size_t)4 * BM * IDXW * sizeof(StagedT) + 64 +
          (size_t)KL * NCONS * 128 * sizeof(float4);
 }
 // how W is held: KS k-groups in the consumers' registers (8 registers each), KL in LDS (8 KB each), the rest streamed.
@@ -571,7 +588,7 @@ int64_t csl_sage_fwd_mfma_scratch(int32_t H, int32_t out) {
   int KS, KL;
   split_for(2 * H / 8, KS, KL);
   if (H < 4 || H % 4 != 0 || out < 1 || out > 256 || lds_for(H, out, KL) > 160 * 1024 - 64) return CSL_E_INVALID;
-  return (int64_t)(2 * H / 8) * ntp_for(out) * 64 * 4 + 128;   // packed W + a zero row
+  return (int64_t)(2 * H / 8) * ntp_for(out) * 64 * 4 + 4 * ZROW4;   // packed W + a zero row
 }
 
 int csl_sage_fwd_mfma_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
@@ -604,7 +621,7 @@ int csl_sage_fwd_mfma_f32(const int32_t* indptr, const int32_t* indices, const i
   const int NTp = ntp_for(out), KQ = 2 * H / 8;
   hipStream_t st = (hipStream_t)stream;
   const long long nw = (long long)KQ * NTp * 64;
-  hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((nw + 32 + 255) / 256)), dim3(256), 0, st, W, (long long)ldw, (int)out, KQ, NTp,
+  hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((nw + ZROW4 + 255) / 256)), dim3(256), 0, st, W, (long long)ldw, (int)out, KQ, NTp,
                      reinterpret_cast<float4*>(wpack));
   FwdArgs a;
   a.indptr = indptr, a.indices = indices, a.self_ids = self_ids, a.rowmap = rowmap;

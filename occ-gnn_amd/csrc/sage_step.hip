@@ -32,6 +32,9 @@ namespace {
 
 thread_local char s_err[200];
 
+// every layer defers a bias sum and possibly a weight-gradient slab sum, the step one loss sum: one launch finishes them
+static_assert(2 * CSL_MAX_LAYERS + 1 <= CSL_REDUCE_MULTI_MAX, "csl_reduce_multi_f32 takes the step's second stages in one call");
+
 // GEMM row counts repeat from minibatch to minibatch (a plan per shape: gemm_lt.hip): multiples of row_pad for tall
 // operands, of 256 below that (a rank of an N-GPU job sees a few hundred to a few thousand rows per layer)
 inline int64_t pad_rows(int64_t m, int64_t row_pad) {
@@ -243,12 +246,14 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
                       ws + o.y[k], out, 0, 1, biases[k], k + 1 < L ? 1 : 0, stream));
   }
   // the second stages, collected: (source, blocks, width, destination)
-  const float* r_src[12];
-  float* r_dst[12];
-  int64_t r_nblk[12];
-  int32_t r_h[12];
+  // (a step defers at most 2 L + 1 second stages: see the static_assert next to CSL_MAX_LAYERS below)
+  const float* r_src[CSL_REDUCE_MULTI_MAX];
+  float* r_dst[CSL_REDUCE_MULTI_MAX];
+  int64_t r_nblk[CSL_REDUCE_MULTI_MAX];
+  int32_t r_h[CSL_REDUCE_MULTI_MAX];
   int nr = 0;
   auto defer = [&](const float* src, int64_t nblk, int32_t h, float* dst) {
+    if (nr >= CSL_REDUCE_MULTI_MAX) return;   // (cannot happen: asserted at compile time)
     r_src[nr] = src, r_nblk[nr] = nblk, r_h[nr] = h, r_dst[nr] = dst;
     nr++;
   };
@@ -449,12 +454,14 @@ int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_s
     STEP(csl_gemm_f32(0, 1, o.mp[k], out, 2 * (int64_t)in, ws + o.cat[k], 2 * (int64_t)in, 0, weights[k], 2 * (int64_t)in, 0,
                       ws + o.y[k], out, 0, 1, biases[k], k + 1 < L ? 1 : 0, stream));
   }
-  const float* r_src[12];
-  float* r_dst[12];
-  int64_t r_nblk[12];
-  int32_t r_h[12];
+  // (a step defers at most 2 L + 1 second stages: see the static_assert next to CSL_MAX_LAYERS below)
+  const float* r_src[CSL_REDUCE_MULTI_MAX];
+  float* r_dst[CSL_REDUCE_MULTI_MAX];
+  int64_t r_nblk[CSL_REDUCE_MULTI_MAX];
+  int32_t r_h[CSL_REDUCE_MULTI_MAX];
   int nr = 0;
   auto defer = [&](const float* src, int64_t nblk, int32_t h, float* dst) {
+    if (nr >= CSL_REDUCE_MULTI_MAX) return;   // (cannot happen: asserted at compile time)
     r_src[nr] = src, r_nblk[nr] = nblk, r_h[nr] = h, r_dst[nr] = dst;
     nr++;
   };

@@ -57,7 +57,7 @@ def _float64_reference(trav, feats, labels, weights, biases, n_nodes):
     grads = []
     for w, b in zip(ws, bs):
         grads += [w.grad, b.grad]
-    return float(loss), grads
+    return float(loss.detach()), grads
 
 
 @pytest.mark.parametrize("fused_deepest_layer", [True, False])

@@ -78,7 +78,8 @@ def test_ring_too_small_is_reported(abi):
 def test_frontier_capacity_overflow_is_flagged(abi):
     from cslicer import l0
     indptr, indices = l0.synth_graph(5000, 30.0, seed=2)
-    e = abi.Engine(indptr, indices, fanouts=(10, 10), max_batch=64, frontier_cap=[0, 100, 0])
+    # recover=False: the C ABI's behaviour (the wrapper's replay-based recovery is tests/test_gpu_recover.py)
+    e = abi.Engine(indptr, indices, fanouts=(10, 10), max_batch=64, frontier_cap=[0, 100, 0], recover=False)
     e.submit_seeds([np.arange(64)])
     with pytest.raises(abi.CslError) as ei:
         e.meta(0)

@@ -72,17 +72,21 @@ def _dp_rank_main(rank, world, port, q):
         # batch 250 over 3 ranks: chunks of 84 / 84 / 82; the epoch's last minibatch is short
         t = DataParallelTrainer(indptr, indices, feats, labels, 5, rank, world, dist, batch=250, fanouts=(10, 5),
                                 streams=3, hidden=16, lr=1e-2, seed=3)
+        # the ranks' mt19937 streams differ (rank-dependent seed): the same seed list draws different neighbourhoods
+        from cslicer import splitgnn
+        t.eng.submit_seeds([perm[:64]], slot=0)
+        probe = splitgnn.slices_of(t.eng, 0, 0)[1][0].in_nodes.cpu().numpy().copy()
         t.set_nodes(perm[:250 * 7 + 100 * (world > 2)])
-        losses = t.run(12)
+        losses = t.run(24)
         tl = torch.tensor(losses, dtype=torch.float64)
         dist.all_reduce(tl)     # a minibatch's loss = sum of the ranks' shares (each already divided by its seed count)
         w = torch.cat([p.detach().reshape(-1).cpu() for p in t.model.parameters()])
         t.close()
         dist.barrier()
-        q.put((rank, tl.tolist(), w.numpy()))
+        q.put((rank, tl.tolist(), w.numpy(), probe))
         dist.destroy_process_group()
     except Exception as ex:
-        q.put((rank, "error: " + repr(ex), None))
+        q.put((rank, "error: " + repr(ex), None, None))
         raise
 
 
@@ -106,8 +110,13 @@ def test_data_parallel_ranks_stay_identical_and_learn(world):
     for g in got[1:]:
         np.testing.assert_array_equal(g[2], got[0][2])
         np.testing.assert_allclose(g[1], got[0][1])
+        # every rank samples its own chunk with its own mt19937 stream (seed 5489 + 7919 rank)
+        assert g[3].shape != got[0][3].shape or not np.array_equal(g[3], got[0][3])
+    # Everything here is a function of the seeds (node order, weights, one mt19937 stream per rank, a deterministic
+    # step and reduction), so the trajectory is the same in every run; "learns" is read off windows of six steps of the
+    # 24, not off single noisy minibatch losses
     losses = got[0][1]
-    assert all(np.isfinite(losses)) and np.mean(losses[-3:]) < 0.92 * np.mean(losses[:3]), losses
+    assert all(np.isfinite(losses)) and np.mean(losses[-6:]) < 0.9 * np.mean(losses[:6]), losses
 
 
 def test_data_parallel_world_of_one_is_the_single_gpu_trainer():
