@@ -66,6 +66,13 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on one GPU)")
     ap.add_argument("--e2e-steps", type=int, default=2048,
                     help="end-to-end training minibatches for the secondary iters/s figure (0 = skip)")
+    ap.add_argument("--e2e-gat-steps", type=int, default=256,
+                    help="one GPU: training minibatches of the GAT leg (BASELINE config 5's shape: 3 layers, 8 heads x 32, "
+                         "fanout 10/10/10, batch 1024; reported as e2e_gat; 0 = skip)")
+    ap.add_argument("--hub-probe", action="store_true",
+                    help="one GPU: also train on a Zipf 'hub' graph and the uniform graph of the same size (profiles/hub_probe.py: "
+                         "1 M nodes, degree 40, half of every row's neighbours drawn from 1000 popular nodes) and report both "
+                         "rates as e2e_hub_probe: by-source lists of thousands of entries are gathered cooperatively")
     ap.add_argument("--no-e2e-multi", action="store_true", help="several GPUs: skip the split-parallel training leg")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not measure roofline.traffic in this run (two short child runs of this workload under rocprofv3 "
@@ -653,6 +660,31 @@ def main():
             "scaling": "strong",
         }
 
+    # ---- BASELINE config 5's model on ONE GPU: 3-layer GAT, 8 heads x 32, fanout 10/10/10, batch 1024 (the reference has a
+    # stub layer only, python/layers/dist_gatconv.py:3-6 + bipartite.py:75-80: defined GATConv-style here, "parity
+    # unpinned"); the attention aggregation is HBM-bound gather work, the projections are library GEMMs
+    def e2e_gat_leg():
+        from cslicer.train import Trainer, synthetic_node_data
+        gfan, heads, hid, n_st = (10, 10, 10), 8, 32, 16
+        feats = lambda own: synthetic_node_data(N, args.e2e_feat, args.e2e_classes, seed=0, rows=own)[0]  # noqa: E731
+        labels = lambda own: synthetic_node_data(N, 1, args.e2e_classes, seed=0, rows=own)[1]            # noqa: E731
+        tr = Trainer(indptr, indices, feats, labels, args.e2e_classes, rank=0, world=1, fanouts=gfan, batch=B, streams=n_st,
+                     hidden=hid, device=device, dist=None, model="gat", heads=heads, feat_dim=args.e2e_feat)
+        tr.set_nodes(perm)
+        steps = args.e2e_gat_steps
+        after = (32 + steps) % tr.n_batches
+        tr.run(32, then=(32, steps))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.run(steps, first_batch=32, then=(after, n_st))   # (slices as many rounds as it trains)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tr.close()
+        return {"iters_per_sec": steps / dt, "ms_per_iter": 1e3 * dt / steps, "steps": steps,
+                "config": "3-layer GAT, %d heads x %d, fanout %s, batch %d, 1 part = 1 GPU, features %d, classes %d, fp32, "
+                          "Adam; slice+gather+fwd+bwd+step (BASELINE config 5's shape on one GPU)" % (
+                              heads, hid, "/".join(map(str, gfan)), B, args.e2e_feat, args.e2e_classes)}
+
     # ---- the same step DATA-parallel (several GPUs only): every GPU holds graph + features, trains 1/N of each minibatch
     # with the single-GPU native step, one gradient all-reduce per step (cslicer.train.DataParallelTrainer)
     def e2e_dp_leg():
@@ -831,6 +863,24 @@ def main():
     if args.e2e_steps > 0 and (world == 1 or not args.no_e2e_multi):
         if world == 1:
             out["e2e"] = e2e_leg()
+            if args.hub_probe:
+                try:
+                    import subprocess
+                    probe = os.path.join(ROOT, "profiles", "hub_probe.py")
+                    res = {}
+                    for kind in ("uniform", "hub"):
+                        o = subprocess.run([sys.executable, probe, kind], capture_output=True, text=True, timeout=600).stdout
+                        res[kind] = float(o.strip().splitlines()[-1].split(":")[1].split()[0])
+                    res["hub_over_uniform"] = res["hub"] / res["uniform"]
+                    res["config"] = "native step, 1 M nodes, degree 40, fanout 15/10/5, batch 1024 (profiles/hub_probe.py)"
+                    out["e2e_hub_probe"] = res
+                except Exception as ex:
+                    out["e2e_hub_probe"] = {"error": repr(ex)[:300]}
+            if args.e2e_gat_steps > 0 and args.e2e_model == "sage":
+                try:
+                    out["e2e_gat"] = e2e_gat_leg()
+                except Exception as ex:   # a second, optional figure: never takes the line with it
+                    out["e2e_gat"] = {"error": repr(ex)[:300]}
         else:
             partial = {}
 

@@ -156,6 +156,18 @@ int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, co
                            int64_t ldg, const float* y, int64_t ldy, int64_t n_src, int64_t n_pad, float* out,
                            int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream);
 
+/* The same where the slice by source has HUB lists (csl_layer_meta.t_max_len > CSL_T_SORTED_MAX: a node that thousands
+ * of the minibatch's rows sampled; the reference's backward walks every edge with its own thread for the same reason,
+ * src/gnn/sage.cu:20-28): rows with longer lists are summed by many workgroups, a segment of the slice's entries each,
+ * and added to the row with fp32 atomics (the order of those few adds per element is the only non-determinism); every
+ * other row exactly as in csl_sage_cat_bwd_t_f32, same masks, padding and column sums.  t_entries = t_indptr[n_src]
+ * (csl_layer_meta.off[CSL_T_INDICES]: the host knows it).  scratch: csl_sage_cat_bwd_t_hub_scratch(n_pad, H) floats =
+ * [2 * blocks][H] per-block column sums (colsum == NULL leaves them there: nblk = scratch floats / H). */
+int64_t csl_sage_cat_bwd_t_hub_scratch(int64_t n_pad, int32_t H);
+int csl_sage_cat_bwd_t_hub_f32(const int32_t* t_indptr, const int32_t* t_indices, int64_t t_entries, const int32_t* indptr,
+                               const float* gcat, int64_t ldg, const float* y, int64_t ldy, int64_t n_src, int64_t n_pad,
+                               float* out, int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream);
+
 /* out[r, :] = (y == NULL || y[r, :] > 0) ? g[r, :] : 0 for r < n, zero rows for n <= r < n_pad;
  * colsum[c] = sum_r out[r, c]: ReLU backward + row padding of the GEMM operand + bias gradient in one pass
  * (two-stage reduction, no atomics, nothing to pre-zero).  scratch: csl_relu_bwd_colsum_scratch(n_pad, H) floats =
@@ -264,8 +276,10 @@ typedef struct {
   int64_t n_out;
   int64_t n_in;
   /* csl_layer_meta.t_max_len of the slice: above CSL_T_SORTED_MAX (a hub node's list: one wave would walk thousands of
-   * entries) the layer's input gradient is scattered with atomics (csl_sage_cat_bwd_f32) instead of gathered */
+   * entries) the layer's input gradient is gathered by csl_sage_cat_bwd_t_hub_f32 (hub rows by many workgroups) */
   int64_t t_max_len;
+  /* entries of the slice by source (t_indptr[n_in]): csl_layer_meta.off[CSL_T_INDICES] of the part */
+  int64_t t_entries;
 } csl_sage_slice;
 int64_t csl_sage_fwd_bwd_workspace(int32_t n_layers, const int32_t* dims, const csl_sage_slice* slices, int64_t row_pad,
                                    int32_t n_slabs);

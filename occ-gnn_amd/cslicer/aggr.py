@@ -23,7 +23,7 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_gemm_save_plans", "csl_gemm_load_plans", "csl_softmax_ce_partial_f32", "csl_reduce_multi_f32",
            "csl_sage_rank_fwd_bwd_f32", "csl_sage_rank_workspace", "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch",
            "csl_gat_bwd_t_f32", "csl_sage_fwd_mfma_f32", "csl_sage_fwd_mfma_scratch", "csl_sage_step_timing",
-           "csl_sage_step_timing_read"]
+           "csl_sage_step_timing_read", "csl_sage_cat_bwd_t_hub_f32", "csl_sage_cat_bwd_t_hub_scratch"]
 _ready = False
 
 
@@ -59,6 +59,9 @@ def _lib():
         L.csl_sage_cat_bwd_t_f32.argtypes = [vp, vp, vp, vp, i64, vp, i64, i64, i64, vp, i64, vp, vp, i32, vp]
         L.csl_sage_cat_bwd_t_scratch.argtypes = [i64, i32]
         L.csl_sage_cat_bwd_t_scratch.restype = i64
+        L.csl_sage_cat_bwd_t_hub_f32.argtypes = [vp, vp, i64, vp, vp, i64, vp, i64, i64, i64, vp, i64, vp, vp, i32, vp]
+        L.csl_sage_cat_bwd_t_hub_scratch.argtypes = [i64, i32]
+        L.csl_sage_cat_bwd_t_hub_scratch.restype = i64
         L.csl_gemm_f32.argtypes = [i32, i32, i64, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, vp, i32, vp]
         L.csl_gemm_last_error.restype = C.c_char_p
         L.csl_sum_slabs_f32.argtypes = [vp, i64, i32, vp, vp]
@@ -341,17 +344,29 @@ def weight_grad_slabs(gy, x, n_slabs):
     return slabs[n_slabs]
 
 
-def sage_cat_bwd_t(t_indptr, t_indices, indptr, gcat, y, n_src, n_pad):
+def sage_cat_bwd_t(t_indptr, t_indices, indptr, gcat, y, n_src, n_pad, hub=False):
     """Gradient of sage_cat's CSR form w.r.t. x as a gather over the slice by source (engine flag FLAG_TRANSPOSE),
-    masked by y > 0 (y None: unmasked), rows padded with zeros to n_pad; returns (out [n_pad, H], column sums [H])."""
+    masked by y > 0 (y None: unmasked), rows padded with zeros to n_pad; returns (out [n_pad, H], column sums [H]).
+    hub: the slice has lists longer than T_SORTED_MAX entries (Slice.t_max_len): those rows are summed by many
+    workgroups (csl_sage_cat_bwd_t_hub_f32)."""
     gcat = _f32(gcat)
     H = gcat.shape[1] // 2
     out = torch.empty((n_pad, H), dtype=torch.float32, device=gcat.device)
     L = _lib()
+    nul = C.c_void_p(0)
+    if hub:
+        buf = torch.empty((H + max(int(L.csl_sage_cat_bwd_t_hub_scratch(n_pad, H)), 1),), dtype=torch.float32,
+                          device=gcat.device)
+        _chk(L.csl_sage_cat_bwd_t_hub_f32(_p(_i32(t_indptr)), _p(_i32(t_indices)), t_indices.numel(), _p(_i32(indptr)),
+                                          _p(gcat), gcat.stride(0), _p(y) if y is not None else nul,
+                                          y.stride(0) if y is not None else 0, n_src, n_pad, _p(out), out.stride(0),
+                                          C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr() + 4 * H), H, _stream()),
+             "csl_sage_cat_bwd_t_hub_f32")
+        return out, buf[:H]
     buf = torch.empty((H + max(int(L.csl_sage_cat_bwd_t_scratch(n_pad, H)), 1),), dtype=torch.float32,
                       device=gcat.device)
     _chk(L.csl_sage_cat_bwd_t_f32(_p(_i32(t_indptr)), _p(_i32(t_indices)), _p(_i32(indptr)), _p(gcat), gcat.stride(0),
-                                  _p(y) if y is not None else C.c_void_p(0), y.stride(0) if y is not None else 0,
+                                  _p(y) if y is not None else nul, y.stride(0) if y is not None else 0,
                                   n_src, n_pad, _p(out), out.stride(0), C.c_void_p(buf.data_ptr()),
                                   C.c_void_p(buf.data_ptr() + 4 * H), H, _stream()), "csl_sage_cat_bwd_t_f32")
     return out, buf[:H]
@@ -361,7 +376,7 @@ class SageSlice(C.Structure):
     """csl_sage_slice (cslicer_aggr.h)"""
     _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("self_ids_in", C.c_void_p),
                 ("t_indptr", C.c_void_p), ("t_indices", C.c_void_p), ("n_out", C.c_int64), ("n_in", C.c_int64),
-                ("t_max_len", C.c_int64)]
+                ("t_max_len", C.c_int64), ("t_entries", C.c_int64)]
 
 
 STEP_GROUPS = ("fused_forward", "gemm", "aggregation", "other")
@@ -417,6 +432,7 @@ class SageStep(object):
                 raise ValueError("layer %d has no slice by source: create the engine with flags=FLAG_TRANSPOSE" % k)
             c.t_indptr, c.t_indices = (s.ptr(A.T_INDPTR), s.ptr(A.T_INDICES)) if k else (None, None)
             c.n_out, c.n_in, c.t_max_len = s.n_out, s.n_in, s.t_max_len
+            c.t_entries = s.count(A.T_INDICES) if k else 0
         L = _lib()
         need = L.csl_sage_fwd_bwd_workspace(self.L, self._dims, self._sl, self.row_pad, self.n_slabs)
         if need < 0:

@@ -316,7 +316,7 @@ class _SageModelLocal(torch.autograd.Function):
             sl = sls[k]
             # gradient w.r.t. layer k-1's pre-activation output, padded like its GEMM operand, and its bias sums
             gyp, gb = aggr.sage_cat_bwd_t(sl.t_indptr, sl.t_indices, sl.indptr, _input_grad(gyp, ws[k]), ys[k - 1], sl.n_in,
-                                          cats[k - 1].shape[0])
+                                          cats[k - 1].shape[0], hub=sl.t_max_len > _abi.T_SORTED_MAX)
         return (None, None) + tuple(grads)
 
 
@@ -408,8 +408,7 @@ class DistSAGEModel(nn.Module):
         """A single part holding every node (one GPU): each layer is one `_SageLayerLocal` node.  `feat_table` is
         the resident [N, F] feature matrix; the deepest layer indexes it through its slice's in_nodes."""
         L = len(slices)
-        if (L > 1 and all(slices[l][part].t_indptr.numel() and slices[l][part].t_max_len <= _abi.T_SORTED_MAX
-                          for l in range(L - 1))):
+        if L > 1 and all(slices[l][part].t_indptr.numel() for l in range(L - 1)):
             # the engine emitted the slices by source: one node for the model, gathered input gradients
             args = []
             for k, conv in enumerate(self.convs):

@@ -608,7 +608,9 @@ __global__ __launch_bounds__(BLK) void k_sage_cat_bwd_t(const int* __restrict__ 
                                                         long long ldg, const float* __restrict__ y, long long ldy,
                                                         long long n_src, long long n_pad, float* __restrict__ out,
                                                         long long ldo, float* __restrict__ partial, int H,
-                                                        long long rows_per_block) {
+                                                        long long rows_per_block, int thr) {
+  // thr > 0: rows whose list is longer than thr entries are LEFT AT ZERO here (hub nodes: one wave walking thousands of
+  // entries); k_sage_cat_bwd_t_hub / _hubfin fill them in
   constexpr int RPB = BLK / G;
   const int lane = threadIdx.x % G, sub = threadIdx.x / G;
   const long long r0 = (long long)blockIdx.x * rows_per_block;
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(BLK) void k_sage_cat_bwd_t(const int* __restrict__ 
     float4 colacc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (long long u = r0 + sub; u < r_end; u += RPB) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (u < n_src && c < H) {
+      if (u < n_src && c < H && !(thr > 0 && tptr[u + 1] - tptr[u] > thr)) {
         const int j0 = tptr[u], j1 = tptr[u + 1];
         float4 a = make_float4(1.f, 1.f, 1.f, 1.f);
         if (y) a = *reinterpret_cast<const float4*>(y + u * ldy + c);
@@ -662,6 +664,108 @@ __host__ __device__ inline long long tb_rows(long long n_pad) {
   long long r = 64;
   while ((n_pad + r - 1) / r > 2048) r *= 2;
   return r;
+}
+
+// ---- hub lists.  A node that thousands of the minibatch's rows sampled has a list of thousands of entries in the slice
+// by source (power-law graphs; src/gnn/sage.cu:20-28 walks every edge with its own thread for the same reason).
+// k_sage_cat_bwd_t leaves such rows at zero (thr); here the ENTRIES of the slice are cut into segments of HUB_SEG, a
+// workgroup per segment: it finds the rows its segment overlaps (binary search in t_indptr), and for every hub row among
+// them sums its part of the list -- G lanes per column quad, the BLK / G lane groups striding over the entries, one LDS
+// reduction -- and adds the partial sum to the row with fp32 atomics (a hub of 5,000 entries: 10 segments, 10 adds
+// per element; the order of those adds is the only non-determinism left).  Segments without a hub entry cost two loads.
+constexpr int HUB_SEG = 512;
+template <int G>
+__global__ __launch_bounds__(BLK) void k_sage_cat_bwd_t_hub(const int* __restrict__ tptr, const int* __restrict__ trow,
+                                                            const int* __restrict__ indptr, const float* __restrict__ gcat,
+                                                            long long ldg, long long n_src, float* __restrict__ out,
+                                                            long long ldo, int H, int thr) {
+  constexpr int RPB = BLK / G;
+  const int lane = threadIdx.x % G, sub = threadIdx.x / G;
+  const long long total = tptr[n_src];
+  const long long e0 = (long long)blockIdx.x * HUB_SEG, e1 = e0 + HUB_SEG < total ? e0 + HUB_SEG : total;
+  if (e0 >= e1) return;
+  long long lo = 0, hi = n_src;   // the first row whose list ends beyond e0 (block-uniform: every thread searches)
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (tptr[mid + 1] > e0) hi = mid; else lo = mid + 1;
+  }
+  long long lo2 = lo, hi2 = n_src;   // the first row whose list starts at or beyond e1
+  while (lo2 < hi2) {
+    const long long mid = (lo2 + hi2) >> 1;
+    if (tptr[mid] >= e1) hi2 = mid; else lo2 = mid + 1;
+  }
+  // the hub rows among [lo, lo2): looked for by all threads at once (a segment of short lists overlaps hundreds of rows)
+  __shared__ int s_hub[HUB_SEG / (CSL_T_SORTED_MAX + 1) + 4];   // (at most 2 + 510 / 129 lists longer than the threshold overlap a segment)
+  __shared__ int s_nhub;
+  __shared__ float4 s_part[BLK];
+  if (threadIdx.x == 0) s_nhub = 0;
+  __syncthreads();
+  for (long long u = lo + threadIdx.x; u < lo2; u += BLK)
+    if (tptr[u + 1] - tptr[u] > thr) s_hub[atomicAdd(&s_nhub, 1)] = (int)(u - lo);
+  __syncthreads();
+  const int nhub = s_nhub;
+  for (int q = 0; q < nhub; q++) {
+    const long long u = lo + s_hub[q];
+    const long long j0 = tptr[u], j1 = tptr[u + 1];
+    const long long a0 = j0 > e0 ? j0 : e0, a1 = j1 < e1 ? j1 : e1;
+    for (int c0 = 0; c0 < H; c0 += G * 4) {   // block-uniform
+      const int c = c0 + lane * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < H) {
+        for (long long j = a0 + sub; j < a1; j += RPB) {
+          const int t = trow[j];
+          const int r = t < 0 ? ~t : t;
+          const int d = indptr[r + 1] - indptr[r];
+          const float4 v = *reinterpret_cast<const float4*>(gcat + (long long)r * ldg + (t < 0 ? 0 : H) + c);
+          const float w = t < 0 ? 1.f : 1.f / (float)(d > 1 ? d : 1);
+          acc.x += w * v.x, acc.y += w * v.y, acc.z += w * v.z, acc.w += w * v.w;
+        }
+      }
+      __syncthreads();
+      s_part[threadIdx.x] = acc;
+      __syncthreads();
+      if (sub == 0 && c < H) {
+        for (int k = 1; k < RPB; k++) add4(acc, s_part[k * G + lane]);
+        float* o = out + u * ldo + c;
+        atomicAdd(o, acc.x), atomicAdd(o + 1, acc.y), atomicAdd(o + 2, acc.z), atomicAdd(o + 3, acc.w);
+      }
+    }
+  }
+}
+
+// the hub rows' ReLU mask and their share of the column sums (everything k_sage_cat_bwd_t does after a row's sum)
+template <int G>
+__global__ __launch_bounds__(BLK) void k_sage_cat_bwd_t_hubfin(const int* __restrict__ tptr, const float* __restrict__ y,
+                                                               long long ldy, long long n_src, float* __restrict__ out,
+                                                               long long ldo, float* __restrict__ partial, int H,
+                                                               long long rows_per_block, int thr) {
+  constexpr int RPB = BLK / G;
+  const int lane = threadIdx.x % G, sub = threadIdx.x / G;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r_end = r0 + rows_per_block < n_src ? r0 + rows_per_block : n_src;
+  __shared__ float4 s_sum[BLK];
+  for (int c0 = 0; c0 < H; c0 += G * 4) {
+    const int c = c0 + lane * 4;
+    float4 colacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long u = r0 + sub; u < r_end; u += RPB) {
+      if (c < H && tptr[u + 1] - tptr[u] > thr) {
+        float4 v = *reinterpret_cast<const float4*>(out + u * ldo + c);
+        if (y) {
+          const float4 a = *reinterpret_cast<const float4*>(y + u * ldy + c);
+          v.x = a.x > 0.f ? v.x : 0.f, v.y = a.y > 0.f ? v.y : 0.f, v.z = a.z > 0.f ? v.z : 0.f, v.w = a.w > 0.f ? v.w : 0.f;
+          *reinterpret_cast<float4*>(out + u * ldo + c) = v;
+        }
+        add4(colacc, v);
+      }
+    }
+    __syncthreads();
+    s_sum[threadIdx.x] = colacc;
+    __syncthreads();
+    if (sub == 0 && c < H) {
+      for (int k = 1; k < RPB; k++) add4(colacc, s_sum[k * G + lane]);
+      *reinterpret_cast<float4*>(partial + (long long)blockIdx.x * H + c) = colacc;
+    }
+  }
 }
 
 // k_softmax_ce: cross-entropy of one minibatch (train.py:86 loss_fn) forward AND backward in one pass:
@@ -1184,7 +1288,7 @@ int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, co
 #define LAUNCH_BWD_T(G)                                                                                           \
   hipLaunchKernelGGL(k_sage_cat_bwd_t<G>, dim3((unsigned)blocks), dim3(BLK), 0, st, t_indptr, t_indices, indptr, gcat, \
                      (long long)ldg, y, (long long)ldy, (long long)n_src, (long long)n_pad, out, (long long)ldo, scratch, \
-                     (int)H, rpb)
+                     (int)H, rpb, 0)
     if (H > 128) LAUNCH_BWD_T(64);
     else if (H > 64) LAUNCH_BWD_T(32);
     else LAUNCH_BWD_T(16);
@@ -1192,6 +1296,47 @@ int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, co
   }
   // colsum == NULL: the per-block sums stay in scratch[blocks][H] for the caller's own second stage (csl_reduce_multi_f32)
   if (colsum) hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((H + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, (int)H, colsum);
+  return done();
+}
+
+int64_t csl_sage_cat_bwd_t_hub_scratch(int64_t n_pad, int32_t H) {
+  if (n_pad < 0 || H < 4 || H % 4 != 0) return CSL_E_INVALID;
+  const long long rpb = tb_rows(n_pad);
+  return 2 * ((n_pad + rpb - 1) / rpb) * H;   // the ordinary rows' blocks, then the hub rows'
+}
+
+int csl_sage_cat_bwd_t_hub_f32(const int32_t* t_indptr, const int32_t* t_indices, int64_t t_entries, const int32_t* indptr,
+                               const float* gcat, int64_t ldg, const float* y, int64_t ldy, int64_t n_src, int64_t n_pad,
+                               float* out, int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream) {
+  if (n_src < 0 || n_pad < n_src || H < 4 || H % 4 != 0 || t_entries < 0) return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const long long rpb = tb_rows(n_pad);
+  const long long blocks = (n_pad + rpb - 1) / rpb;
+  if (blocks > 0) {
+    if (!out || !scratch || ldo < H || ldo % 4 != 0 || !aligned16(out)) return CSL_E_INVALID;
+    if (n_src > 0 && (!t_indptr || !t_indices || !indptr || !gcat || ldg < 2 * (int64_t)H || ldg % 4 != 0 || !aligned16(gcat)))
+      return CSL_E_INVALID;
+    if (y && (ldy < H || ldy % 4 != 0 || !aligned16(y))) return CSL_E_INVALID;
+    const int thr = CSL_T_SORTED_MAX;
+    const long long segs = (t_entries + HUB_SEG - 1) / HUB_SEG;
+    float* part2 = scratch + blocks * H;
+#define LAUNCH_HUB(G)                                                                                                  \
+  do {                                                                                                                 \
+    hipLaunchKernelGGL(k_sage_cat_bwd_t<G>, dim3((unsigned)blocks), dim3(BLK), 0, st, t_indptr, t_indices, indptr, gcat, \
+                       (long long)ldg, y, (long long)ldy, (long long)n_src, (long long)n_pad, out, (long long)ldo,     \
+                       scratch, (int)H, rpb, thr);                                                                     \
+    if (segs > 0 && n_src > 0)                                                                                         \
+      hipLaunchKernelGGL(k_sage_cat_bwd_t_hub<G>, dim3((unsigned)segs), dim3(BLK), 0, st, t_indptr, t_indices, indptr,  \
+                         gcat, (long long)ldg, (long long)n_src, out, (long long)ldo, (int)H, thr);                    \
+    hipLaunchKernelGGL(k_sage_cat_bwd_t_hubfin<G>, dim3((unsigned)blocks), dim3(BLK), 0, st, t_indptr, y, (long long)ldy, \
+                       (long long)n_src, out, (long long)ldo, part2, (int)H, rpb, thr);                                \
+  } while (0)
+    if (H > 128) LAUNCH_HUB(64);
+    else if (H > 64) LAUNCH_HUB(32);
+    else LAUNCH_HUB(16);
+#undef LAUNCH_HUB
+  }
+  if (colsum) hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((H + 63) / 64)), dim3(BLK), 0, st, scratch, 2 * blocks, (int)H, colsum);
   return done();
 }
 

@@ -336,6 +336,9 @@ __device__ __forceinline__ void consumer_step(const FwdArgs& a, int t, int tile,
   f32x16 acc0, acc1;
 #pragma unroll
   for (int i = 0; i < 16; i++) acc0[i] = bv0, acc1[i] = bv1;   // C starts as the bias of the lane's column
+  // (a tile of padding rows only -- the caller rounds its row count up for the GEMMs that follow -- is act(bias): nothing
+  // to multiply)
+  if ((long long)tile * BM < a.n) {
   const float* ab = A + l31 * lda + 4 * h;
   float4 aa[2];
   aa[0] = *reinterpret_cast<const float4*>(ab);
@@ -399,6 +402,7 @@ __device__ __forceinline__ void consumer_step(const FwdArgs& a, int t, int tile,
         MFMA8(aa[(K0 + i) % 2], bb[i % NB][0], bb[i % NB][1])
       }
     }
+  }
   }
   // C/D of a 32x32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a store instruction writes
   // two 128-byte row segments.  Nothing waits for these stores (a consumer has no load in its queue behind them).

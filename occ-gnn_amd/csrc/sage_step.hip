@@ -46,7 +46,6 @@ inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }  // every buffer
 
 struct Layout {
   int64_t cat[CSL_MAX_LAYERS], y[CSL_MAX_LAYERS], gy[CSL_MAX_LAYERS], gcat[CSL_MAX_LAYERS], mp[CSL_MAX_LAYERS];
-  int64_t gx[CSL_MAX_LAYERS];       // [n_in][in]: a layer with a hub list scatters its input gradient here (atomics)
   bool hub[CSL_MAX_LAYERS];
   // first stages of the step's reductions, each in a buffer of its own: they are all finished by ONE launch at the end
   int64_t slabs[CSL_MAX_LAYERS];    // [n_slabs][out][2 in] of a layer whose weight gradient is computed in row slabs
@@ -74,15 +73,14 @@ bool lay_out(int32_t L, const int32_t* dims, const csl_sage_slice* sl, int64_t r
     o.y[k] = at, at += up4(mp * out);
     o.gy[k] = at, at += up4(mp * out);
     o.gcat[k] = at, at += k > 0 ? up4(mp * 2 * in) : 0;
-    o.hub[k] = k > 0 && sl[k].t_max_len > CSL_T_SORTED_MAX;
-    o.gx[k] = at, at += o.hub[k] ? up4(sl[k].n_in * in) : 0;
+    o.hub[k] = k > 0 && sl[k].t_max_len > CSL_T_SORTED_MAX;   // a hub list: its rows are gathered by many workgroups
     const int64_t wn = out * 2 * in;
     o.slabbed[k] = row_pad > 0 && mp >= row_pad && n_slabs > 1 && mp % n_slabs == 0 && wn % 4 == 0;
     o.slabs[k] = at, at += o.slabbed[k] ? up4(wn * n_slabs) : 0;
-    // gb_k's first stage: written by layer k+1's gather -- or, when that layer has a hub list, by the mask pass behind
-    // its atomic scatter -- (k < L-1), or by the loss pass / relu_bwd_colsum (k = L-1)
+    // gb_k's first stage: written by layer k+1's gather (k < L-1; twice the blocks when that layer has hub lists), or by
+    // the loss pass / relu_bwd_colsum (k = L-1)
     const bool hub_above = k + 1 < L && sl[k + 1].t_max_len > CSL_T_SORTED_MAX;
-    const int64_t part = k + 1 < L ? (hub_above ? csl_relu_bwd_colsum_scratch(mp, (int32_t)out)
+    const int64_t part = k + 1 < L ? (hub_above ? csl_sage_cat_bwd_t_hub_scratch(mp, (int32_t)out)
                                                 : csl_sage_cat_bwd_t_scratch(mp, (int32_t)out)) : 0;
     o.bblocks[k] = out > 0 ? part / out : 0;
     o.bpart[k] = at, at += up4(part);
@@ -299,12 +297,11 @@ int csl_sage_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_sage_s
     // its column sums (gb_{k-1}) stay as per-block partials
     if (o.hub[k]) {
       // a hub's list in the slice by source is thousands of entries, one wave's serial walk (1.3 ms instead of 30 us per
-      // launch on a Zipf graph: profiles/hub_probe.py): this layer scatters with atomics, then masks / pads / sums
-      TSTEP(CSL_STEP_AGGREGATION, csl_sage_cat_bwd_f32(sl[k].indptr, sl[k].indices, sl[k].self_ids_in, sl[k].n_out, ws + o.gcat[k], 2 * (int64_t)in,
-                                ws + o.gx[k], in, sl[k].n_in, in, stream));
-      if (o.mp[k - 1] > 0)
-        TSTEP(CSL_STEP_AGGREGATION, csl_relu_bwd_colsum_f32(ws + o.gx[k], in, ws + o.y[k - 1], in, sl[k].n_in, o.mp[k - 1], ws + o.gy[k - 1], in,
-                                     nullptr, ws + o.bpart[k - 1], in, stream));
+      // launch on a Zipf graph: profiles/hub_probe.py): those rows are summed by a workgroup per segment of entries
+      TSTEP(CSL_STEP_AGGREGATION, csl_sage_cat_bwd_t_hub_f32(sl[k].t_indptr, sl[k].t_indices, sl[k].t_entries, sl[k].indptr,
+                                                              ws + o.gcat[k], 2 * (int64_t)in, ws + o.y[k - 1], in, sl[k].n_in,
+                                                              o.mp[k - 1], ws + o.gy[k - 1], in, nullptr, ws + o.bpart[k - 1],
+                                                              in, stream));
     } else
     TSTEP(CSL_STEP_AGGREGATION, csl_sage_cat_bwd_t_f32(sl[k].t_indptr, sl[k].t_indices, sl[k].indptr, ws + o.gcat[k], 2 * (int64_t)in,
                                 ws + o.y[k - 1], in, sl[k].n_in, o.mp[k - 1], ws + o.gy[k - 1], in, nullptr,

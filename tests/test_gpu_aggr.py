@@ -406,19 +406,27 @@ def test_native_step_matches_the_autograd_path(mods, B, row_pad):
     eng.close()
 
 
-def test_native_step_with_hub_nodes_falls_back_to_the_scatter_form(mods):
-    """A graph whose rows all point at three hubs: the hubs' lists in the slices by source are thousands of entries
-    long (t_max_len > CSL_T_SORTED_MAX), so the native step scatters that layer's input gradient with atomics instead
-    of letting one wave walk the list; same loss and gradients as the autograd path on the same slices."""
-    abi, aggr, sg = mods
-    torch.manual_seed(4)
-    n, deg, F0, hidden, classes, B = 20000, 10, 16, 32, 5, 512
-    rng = np.random.default_rng(4)
+def _hub_graph(n=20000, deg=10, seed=4):
+    """a graph whose rows all point at three hubs"""
+    rng = np.random.default_rng(seed)
     nb = rng.integers(0, n, size=(n, deg))
     nb[:, :3] = np.array([5, 9, 17])
     nb[[5, 9, 17]] = rng.integers(100, n, size=(3, deg))
     indptr = np.arange(n + 1, dtype=np.int64) * deg
     indices = np.sort(nb, axis=1).reshape(-1).astype(np.int64)
+    return indptr, indices, rng
+
+
+def test_native_step_with_hub_nodes_gathers_their_lists_cooperatively(mods, monkeypatch):
+    """A graph whose rows all point at three hubs: the hubs' lists in the slices by source are thousands of entries
+    long (t_max_len > CSL_T_SORTED_MAX).  One wave walking such a list is a serial crawl, so those rows are summed by a
+    workgroup per segment of entries (csl_sage_cat_bwd_t_hub_f32) -- the layer keeps the gather form, no atomic scatter
+    of the whole layer; same loss and gradients as the per-layer autograd path with the atomic scatter on the same
+    slices (src/gnn/sage.cu:20-28 is that scatter in the reference)."""
+    abi, aggr, sg = mods
+    torch.manual_seed(4)
+    n, F0, hidden, classes, B = 20000, 16, 32, 5, 512
+    indptr, indices, rng = _hub_graph(n)
     eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(6, 5, 4), max_batch=B, mode=abi.MODE_GRAPH,
                      flags=abi.FLAG_TRANSPOSE)
     eng.submit_seeds([rng.permutation(n)[:B]])
@@ -427,17 +435,70 @@ def test_native_step_with_hub_nodes_falls_back_to_the_scatter_form(mods):
     feats = torch.randn(n, F0, device="cuda")
     labels = torch.randint(0, classes, (n,), device="cuda")
     model = sg.DistSAGEModel(F0, hidden, classes, n_layers=3).cuda()
-    out = model.forward_local(slices, feats)            # (falls back to one node per layer, atomic scatter)
-    assert type(out.grad_fn).__name__ != "_SageModelLocalBackward"
+    # reference: one autograd node per layer, input gradients scattered with atomics (no slice by source involved)
+    monkeypatch.setattr(sg, "_NO_LOCAL_FUSE", False, raising=False)
+    eng2 = abi.Engine(indptr, indices, n_parts=1, fanouts=(6, 5, 4), max_batch=B, mode=abi.MODE_GRAPH)
+    eng2.submit_seeds([_hub_graph(n)[2].permutation(n)[:B]])
+    slices2 = sg.slices_of(eng2)
+    out2 = model.forward_local(slices2, feats)
+    assert type(out2.grad_fn).__name__ != "_SageModelLocalBackward"
+    loss2 = aggr.SoftmaxCE.apply(out2, slices2[0][0].out_nodes, labels, 1.0 / B)
+    loss2.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    # the one-node autograd path over the slices by source (hub rows cooperatively)
+    model.zero_grad()
+    out = model.forward_local(slices, feats)
+    assert type(out.grad_fn).__name__ == "_SageModelLocalBackward"
     loss = aggr.SoftmaxCE.apply(out, slices[0][0].out_nodes, labels, 1.0 / B)
     loss.backward()
-    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    got_py = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    torch.testing.assert_close(loss.detach(), loss2.detach(), rtol=1e-5, atol=1e-6)
+    assert float((got_py - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    # the native step
     step = aggr.SageStep(model, 256, 4)
     got_loss = torch.zeros(1, device="cuda")
     step([slices[2][0], slices[1][0], slices[0][0]], feats, labels, 1.0 / B, got_loss)
-    torch.testing.assert_close(got_loss[0], loss.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got_loss[0], loss2.detach(), rtol=1e-5, atol=1e-6)
     assert float((step.grads - want).abs().max()) <= 1e-4 * float(want.abs().max())
     eng.close()
+    eng2.close()
+
+
+@pytest.mark.parametrize("H,masked", [(256, True), (64, False), (100, True)])
+def test_hub_lists_by_source_match_the_atomic_scatter(mods, H, masked):
+    """csl_sage_cat_bwd_t_hub_f32 on slices with hub lists (several segments per hub, hubs next to short lists) ==
+    csl_sage_cat_bwd_f32 (atomics) + csl_relu_bwd_colsum_f32."""
+    abi, aggr, sg = mods
+    torch.manual_seed(H)
+    n, B = 20000, 1024
+    indptr, indices, rng = _hub_graph(n)
+    eng = abi.Engine(indptr, indices, n_parts=1, fanouts=(8, 6), max_batch=B, mode=abi.MODE_GRAPH, flags=abi.FLAG_TRANSPOSE)
+    eng.submit_seeds([rng.permutation(n)[:B]])
+    sl = sg.slices_of(eng)[0][0]
+    assert sl.t_max_len > 4 * abi.T_SORTED_MAX
+    n_pad = sl.n_in + 91
+    gcat = torch.randn(sl.n_out, 2 * H, device="cuda")
+    y = torch.randn(n_pad, H, device="cuda") if masked else None
+    out, cs = aggr.sage_cat_bwd_t(sl.t_indptr, sl.t_indices, sl.indptr, gcat, y, sl.n_in, n_pad, hub=True)
+    gx = aggr.sage_cat_bwd(sl.indptr, sl.indices, sl.self_ids_in, gcat, sl.n_out, sl.n_in)
+    want, wcs = aggr.relu_bwd_colsum(gx, y, sl.n_in, n_pad)
+    # (hub rows sum thousands of N(0, 1) terms: compare relative to the row's magnitude)
+    scale = want.abs().max(dim=1, keepdim=True).values.clamp(min=1.0)
+    assert float(((out - want).abs() / scale).max()) <= 1e-5
+    torch.testing.assert_close(cs, wcs, rtol=1e-4, atol=2e-3 * float(want.abs().max()))
+    # a slice WITHOUT hubs through the hub entry point: identical to the plain kernel
+    from cslicer import l0
+    ip2, ix2 = l0.synth_graph(6000, 20.0, seed=2)
+    e2 = abi.Engine(ip2, ix2, n_parts=1, fanouts=(8, 6), max_batch=256, mode=abi.MODE_GRAPH, flags=abi.FLAG_TRANSPOSE)
+    e2.submit_seeds([np.random.default_rng(5).permutation(6000)[:256]])
+    s2 = sg.slices_of(e2)[0][0]
+    g2 = torch.randn(s2.n_out, 2 * H, device="cuda")
+    a_, ca = aggr.sage_cat_bwd_t(s2.t_indptr, s2.t_indices, s2.indptr, g2, None, s2.n_in, s2.n_in + 5, hub=True)
+    b_, cb = aggr.sage_cat_bwd_t(s2.t_indptr, s2.t_indices, s2.indptr, g2, None, s2.n_in, s2.n_in + 5)
+    assert torch.equal(a_, b_)
+    torch.testing.assert_close(ca, cb, rtol=1e-6, atol=1e-6)
+    eng.close()
+    e2.close()
 
 
 @pytest.mark.parametrize("H,masked", [(256, True), (32, False), (100, True)])
