@@ -83,6 +83,19 @@ int csl_gat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, int64_t
                       const float* er, const float* z, int32_t H, int32_t D, float slope, const float* m_in,
                       const float* g_s, const float* g_n, float* g_el, float* g_er, float* g_z, void* stream);
 
+/* csl_gat_bwd_t_f32 with the attention logits' backward (csl_gat_logits_bwd_acc_f32) folded in: g_z [n_pad, H*D] is
+ * WRITTEN complete -- the aggregation's share + g_el a_l (inside the pass over the source rows, where z[u] and the finished
+ * g_el[u] are in registers) + g_er a_r (a second small pass over the n_out destination rows, whose z row is their self
+ * source self_ids_in[r]) --, g_attn_l / g_attn_r [H, D] are the sums over the rows (two-stage), g_er_out [n_out, H] is
+ * zeroed and accumulated here (an output for callers that want it).  No pass re-reads z or read-modify-writes all of g_z.
+ * scratch: csl_gat_bwd_t_fused_scratch(n_pad, n_out, H, D) floats. */
+int64_t csl_gat_bwd_t_fused_scratch(int64_t n_pad, int64_t n_out, int32_t H, int32_t D);
+int csl_gat_bwd_t_fused_f32(const int32_t* t_indptr, const int32_t* t_indices, int64_t n_src, int64_t n_pad, const float* el,
+                            const float* er_out, const float* z, int32_t H, int32_t D, float slope, const float* m_in,
+                            const float* g_s, const float* g_n, const float* attn_l, const float* attn_r,
+                            const int32_t* self_ids_in, int64_t n_out, float* g_er_out, float* g_z, float* g_attn_l,
+                            float* g_attn_r, float* scratch, void* stream);
+
 /* GAT attention logits (DistGATConv.project): el[r, h] = <z[r, h, :], attn_l[h, :]>, er likewise; z [n, H*D],
  * attn_* [H, D], el/er [n, H]; D % 4 == 0, D <= 256, 16-byte aligned.  Backward: g_z [n, H*D] is WRITTEN
  * (g_el a_l + g_er a_r), g_attn_l / g_attn_r [H, D] are the sums over the rows (two-stage, no atomics);

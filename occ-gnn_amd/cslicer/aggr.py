@@ -23,7 +23,8 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_gemm_save_plans", "csl_gemm_load_plans", "csl_softmax_ce_partial_f32", "csl_reduce_multi_f32",
            "csl_sage_rank_fwd_bwd_f32", "csl_sage_rank_workspace", "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch",
            "csl_gat_bwd_t_f32", "csl_sage_fwd_mfma_f32", "csl_sage_fwd_mfma_scratch", "csl_sage_step_timing",
-           "csl_sage_step_timing_read", "csl_sage_cat_bwd_t_hub_f32", "csl_sage_cat_bwd_t_hub_scratch"]
+           "csl_sage_step_timing_read", "csl_sage_cat_bwd_t_hub_f32", "csl_sage_cat_bwd_t_hub_scratch",
+           "csl_gat_bwd_t_fused_f32", "csl_gat_bwd_t_fused_scratch"]
 _ready = False
 
 
@@ -76,6 +77,10 @@ def _lib():
                                                 EXCHANGE_WAIT_FN, vp, vp, vp, vp, i64, vp]
         L.csl_gat_logits_bwd_acc_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, vp, i32, vp, vp, vp, vp]
         L.csl_gat_bwd_t_f32.argtypes = [vp, vp, i64, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
+        L.csl_gat_bwd_t_fused_f32.argtypes = [vp, vp, i64, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, i64, vp, vp,
+                                              vp, vp, vp, vp]
+        L.csl_gat_bwd_t_fused_scratch.argtypes = [i64, i64, i32, i32]
+        L.csl_gat_bwd_t_fused_scratch.restype = i64
         L.csl_gat_finish_fwd_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
         L.csl_gat_finish_bwd_f32.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp, vp]
         L.csl_gat_finish_bwd_scratch.argtypes = [i64, i32, i32]
@@ -820,24 +825,37 @@ class GatLayerLocal(torch.autograd.Function):
         _chk(L.csl_gat_finish_bwd_f32(_p(g), g.stride(0), _p(out), _p(n), _p(s), n_out, H, D, 1 if elu else 0, _p(g_n),
                                       _p(g_s), _p(g_bias), scratch, _stream()), "csl_gat_finish_bwd_f32")
         # ONE gradient buffer for z (padded like the GEMM operand): the aggregation's share, then the logits' share
-        if ctx.by_source is not None:
+        if ctx.by_source is not None and not os.environ.get("CSLICER_GAT_NO_FOLD"):
+            # by source, with the logits' backward folded in: g_z is written complete in one pass over the source rows
+            # plus a small one over the destinations (csl_gat_bwd_t_fused_f32)
             tptr, trow = ctx.by_source
             g_z = torch.empty((z.shape[0], Cw), dtype=torch.float32, device=dev)     # every row is written
-            g_el = torch.empty((n_in, H), dtype=torch.float32, device=dev)
-            g_er_out = torch.zeros((n_out, H), dtype=torch.float32, device=dev)
-            _chk(L.csl_gat_bwd_t_f32(_p(tptr), _p(trow), n_in, z.shape[0], _p(el), _p(er_out), _p(z), H, D, slope, _p(m),
-                                     _p(g_s), _p(g_n), _p(g_el), _p(g_er_out), _p(g_z), _stream()), "csl_gat_bwd_t_f32")
-        else:
-            g_z = torch.zeros((z.shape[0], Cw), dtype=torch.float32, device=dev)
-            g_el = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
             g_er_out = torch.empty((n_out, H), dtype=torch.float32, device=dev)
-            _chk(L.csl_gat_bwd_f32(_p(indptr), _p(indices), n_out, _p(el), _p(er_out), _p(z), H, D, slope, _p(m), _p(g_s),
-                                   _p(g_n), _p(g_el), _p(g_er_out), _p(g_z), _stream()), "csl_gat_bwd_f32")
-        g_er = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
-        scatter_add_rows_(g_er, self_ids_in, g_er_out)              # (a node is the self source of one destination)
-        _chk(L.csl_gat_logits_bwd_acc_f32(_p(z), _p(al), _p(ar), _p(g_el), _p(g_er), n_in, H, D, _p(g_z), 1,
-                                          C.c_void_p(g_al.data_ptr()), C.c_void_p(g_ar.data_ptr()), scratch, _stream()),
-             "csl_gat_logits_bwd_acc_f32")
+            fs = torch.empty((max(int(L.csl_gat_bwd_t_fused_scratch(z.shape[0], n_out, H, D)), 4),), dtype=torch.float32,
+                             device=dev)
+            _chk(L.csl_gat_bwd_t_fused_f32(_p(tptr), _p(trow), n_in, z.shape[0], _p(el), _p(er_out), _p(z), H, D, slope, _p(m),
+                                           _p(g_s), _p(g_n), _p(al), _p(ar), _p(self_ids_in), n_out, _p(g_er_out), _p(g_z),
+                                           C.c_void_p(g_al.data_ptr()), C.c_void_p(g_ar.data_ptr()), _p(fs), _stream()),
+                 "csl_gat_bwd_t_fused_f32")
+        else:
+            if ctx.by_source is not None:
+                tptr, trow = ctx.by_source
+                g_z = torch.empty((z.shape[0], Cw), dtype=torch.float32, device=dev)     # every row is written
+                g_el = torch.empty((n_in, H), dtype=torch.float32, device=dev)
+                g_er_out = torch.zeros((n_out, H), dtype=torch.float32, device=dev)
+                _chk(L.csl_gat_bwd_t_f32(_p(tptr), _p(trow), n_in, z.shape[0], _p(el), _p(er_out), _p(z), H, D, slope, _p(m),
+                                         _p(g_s), _p(g_n), _p(g_el), _p(g_er_out), _p(g_z), _stream()), "csl_gat_bwd_t_f32")
+            else:
+                g_z = torch.zeros((z.shape[0], Cw), dtype=torch.float32, device=dev)
+                g_el = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
+                g_er_out = torch.empty((n_out, H), dtype=torch.float32, device=dev)
+                _chk(L.csl_gat_bwd_f32(_p(indptr), _p(indices), n_out, _p(el), _p(er_out), _p(z), H, D, slope, _p(m), _p(g_s),
+                                       _p(g_n), _p(g_el), _p(g_er_out), _p(g_z), _stream()), "csl_gat_bwd_f32")
+            g_er = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
+            scatter_add_rows_(g_er, self_ids_in, g_er_out)              # (a node is the self source of one destination)
+            _chk(L.csl_gat_logits_bwd_acc_f32(_p(z), _p(al), _p(ar), _p(g_el), _p(g_er), n_in, H, D, _p(g_z), 1,
+                                              C.c_void_p(g_al.data_ptr()), C.c_void_p(g_ar.data_ptr()), scratch, _stream()),
+                 "csl_gat_logits_bwd_acc_f32")
         gw = weight_grad(g_z, xp)
         gx = None
         if ctx.needs_input_grad[0]:

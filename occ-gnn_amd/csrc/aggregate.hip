@@ -368,6 +368,112 @@ __global__ __launch_bounds__(BLK) void k_gat_bwd_t(const int* __restrict__ tptr,
   }
 }
 
+// k_gat_bwd_t with the logits' backward folded in (csl_gat_bwd_t_fused_f32).  A source row's g_el[u, h] is complete when
+// its wave has walked its list, and z[u, :] is already in the wave's registers, so the el half of DistGATConv.project's
+// backward -- g_z[u, h, :] += g_el[u, h] a_l[h, :] and g_attn_l[h, :] += g_el[u, h] z[u, h, :] -- costs no memory pass of
+// its own (k_gat_logits_bwd re-read z and read-modify-wrote all of g_z: 112 us per layer in the config-5 step).  The er
+// half depends on g_er of the DESTINATIONS, complete only when every source row has been walked: it runs afterwards over
+// the destination rows alone (k_gat_logits_bwd_dst: n_out rows, a tenth of the sources).  A workgroup takes
+// rows_per_block source rows, a wave every fourth of them; part_l[block][C] = the block's share of g_attn_l.
+__global__ __launch_bounds__(BLK) void k_gat_bwd_t2(const int* __restrict__ tptr, const int* __restrict__ trow,
+                                                    long long n_src, long long n_pad, const float* __restrict__ el,
+                                                    const float* __restrict__ er, const float* __restrict__ z, int H, int D,
+                                                    float slope, const float* __restrict__ m_in,
+                                                    const float* __restrict__ g_s, const float* __restrict__ g_n,
+                                                    const float* __restrict__ al, float* g_er, float* __restrict__ g_z,
+                                                    float* __restrict__ part_l, long long rows_per_block) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int C = H * D, gsz = D / 4, lpc = (64 / gsz) * gsz, gl = lane % gsz;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r_end = r0 + rows_per_block < n_pad ? r0 + rows_per_block : n_pad;
+  __shared__ float4 s_l[BLK];
+  for (int c0 = 0; c0 < C; c0 += lpc * 4) {   // block-uniform
+    const int c = c0 + lane * 4;
+    const bool on = lane < lpc && c < C;
+    const int h = on ? c / D : 0;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), pl = a4;
+    if (on) a4 = *reinterpret_cast<const float4*>(al + c);
+    for (long long u = r0 + w; u < r_end; u += BLK / 64) {
+      const int j0 = u < n_src ? tptr[u] : 0, j1 = u < n_src ? tptr[u + 1] : 0;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), zv = acc;
+      float elu = 0.f, gel = 0.f;
+      if (u < n_src) {
+        elu = el[u * H + h];
+        if (on) zv = *reinterpret_cast<const float4*>(z + u * C + c);
+      }
+      for (int j = j0; j < j1; j++) {
+        const int r = trow[j];  // (wave-uniform)
+        if (r < 0) continue;    // the node's self entry: attention runs over the sampled edges only
+        const float raw = elu + er[(long long)r * H + h];
+        const float p = expf(leaky(raw, slope) - m_in[(long long)r * H + h]);
+        float dot = 0.f;
+        float4 gn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (on) {
+          gn = *reinterpret_cast<const float4*>(g_n + (long long)r * C + c);
+          dot = gn.x * zv.x + gn.y * zv.y + gn.z * zv.z + gn.w * zv.w;
+        }
+        for (int o = 1; o < gsz; o <<= 1) {  // sum over the head's lane group
+          const float t = __shfl_down(dot, o);
+          if (gl + o < gsz) dot += t;
+        }
+        dot = __shfl(dot, lane - gl);
+        const float gsc = (g_s[(long long)r * H + h] + dot) * p * (raw > 0.f ? 1.f : slope);
+        acc.x += p * gn.x, acc.y += p * gn.y, acc.z += p * gn.z, acc.w += p * gn.w;
+        gel += gsc;   // (every lane of the head's group carries the same value)
+        if (on && c % D == 0) atomicAdd(g_er + (long long)r * H + h, gsc);
+      }
+      if (on) {
+        acc.x += gel * a4.x, acc.y += gel * a4.y, acc.z += gel * a4.z, acc.w += gel * a4.w;   // + g_el a_l
+        *reinterpret_cast<float4*>(g_z + u * C + c) = acc;
+        pl.x += gel * zv.x, pl.y += gel * zv.y, pl.z += gel * zv.z, pl.w += gel * zv.w;       // g_attn_l's share
+      }
+    }
+    __syncthreads();
+    s_l[threadIdx.x] = pl;
+    __syncthreads();
+    if (w == 0 && on) {
+      for (int k = 1; k < BLK / 64; k++) add4(pl, s_l[k * 64 + lane]);
+      *reinterpret_cast<float4*>(part_l + (long long)blockIdx.x * C + c) = pl;
+    }
+  }
+}
+
+// the er half: destination r's logit gradient goes to the z row of its self source
+__global__ __launch_bounds__(BLK) void k_gat_logits_bwd_dst(const float* __restrict__ z, const float* __restrict__ ar,
+                                                            const int* __restrict__ self_ids, const float* __restrict__ g_er,
+                                                            long long n_out, int H, int D, float* __restrict__ g_z,
+                                                            float* __restrict__ part_r, long long rows_per_block) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int C = H * D, gsz = D / 4, lpc = (64 / gsz) * gsz;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r_end = r0 + rows_per_block < n_out ? r0 + rows_per_block : n_out;
+  __shared__ float4 s_r[BLK];
+  for (int c0 = 0; c0 < C; c0 += lpc * 4) {
+    const int c = c0 + lane * 4;
+    const bool on = lane < lpc && c < C;
+    const int h = on ? c / D : 0;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), pr = b4;
+    if (on) b4 = *reinterpret_cast<const float4*>(ar + c);
+    for (long long r = r0 + w; r < r_end; r += BLK / 64) {
+      const long long u = self_ids[r];
+      if (!on || u < 0) continue;
+      const float ge = g_er[r * H + h];
+      const float4 zv = *reinterpret_cast<const float4*>(z + u * C + c);
+      float4 o = *reinterpret_cast<const float4*>(g_z + u * C + c);
+      o.x += ge * b4.x, o.y += ge * b4.y, o.z += ge * b4.z, o.w += ge * b4.w;
+      *reinterpret_cast<float4*>(g_z + u * C + c) = o;
+      pr.x += ge * zv.x, pr.y += ge * zv.y, pr.z += ge * zv.z, pr.w += ge * zv.w;
+    }
+    __syncthreads();
+    s_r[threadIdx.x] = pr;
+    __syncthreads();
+    if (w == 0 && on) {
+      for (int k = 1; k < BLK / 64; k++) add4(pr, s_r[k * 64 + lane]);
+      *reinterpret_cast<float4*>(part_r + (long long)blockIdx.x * C + c) = pr;
+    }
+  }
+}
+
 // ---- fused GraphSAGE layer pieces (one part per GPU and the single-GPU trainer) --------------------------
 // k_sage_cat: builds the operand of Linear(2*in, out) in ONE pass (dist_sageconv.py:66-80: self_gather, gather,
 // slice_owned_nodes, mean, concat):
@@ -1110,6 +1216,47 @@ int csl_gat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, int64_t
   hipLaunchKernelGGL(k_gat_bwd_t, dim3((unsigned)((n_pad + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, (hipStream_t)stream,
                      t_indptr, t_indices, (long long)n_src, (long long)n_pad, el, er, z, (int)H, (int)D, slope, m_in, g_s,
                      g_n, g_el, g_er, g_z);
+  return done();
+}
+
+static long long gat_t_rows(long long n) {   // source rows per workgroup of k_gat_bwd_t2: at most ~4096 workgroups
+  long long r = 16;
+  while ((n + r - 1) / r > 4096) r *= 2;
+  return r;
+}
+
+int64_t csl_gat_bwd_t_fused_scratch(int64_t n_pad, int64_t n_out, int32_t H, int32_t D) {
+  if (n_pad < 0 || n_out < 0 || H < 1 || D < 4 || D % 4 != 0 || D > 256) return CSL_E_INVALID;
+  const long long r1 = gat_t_rows(n_pad), r2 = gat_t_rows(n_out);
+  return ((n_pad + r1 - 1) / r1 + (n_out + r2 - 1) / r2) * (int64_t)H * D;
+}
+
+int csl_gat_bwd_t_fused_f32(const int32_t* t_indptr, const int32_t* t_indices, int64_t n_src, int64_t n_pad, const float* el,
+                            const float* er_out, const float* z, int32_t H, int32_t D, float slope, const float* m_in,
+                            const float* g_s, const float* g_n, const float* attn_l, const float* attn_r,
+                            const int32_t* self_ids_in, int64_t n_out, float* g_er_out, float* g_z, float* g_attn_l,
+                            float* g_attn_r, float* scratch, void* stream) {
+  if (n_src < 0 || n_pad < n_src || n_out < 0 || H < 1 || D < 4 || D % 4 != 0 || D > 256 || !g_attn_l || !g_attn_r)
+    return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int C = H * D;
+  const long long r1 = gat_t_rows(n_pad), r2 = gat_t_rows(n_out);
+  const long long b1 = (n_pad + r1 - 1) / r1, b2 = (n_out + r2 - 1) / r2;
+  if (b1 > 0) {
+    if (!g_z || !aligned16(g_z) || !scratch || !aligned16(scratch) || !attn_l || !aligned16(attn_l)) return CSL_E_INVALID;
+    if (n_src > 0 && (!t_indptr || !el || !z || !aligned16(z) || !er_out || !m_in || !g_s || !g_n || !aligned16(g_n) || !g_er_out))
+      return CSL_E_INVALID;
+    if (n_out > 0 && hipMemsetAsync(g_er_out, 0, sizeof(float) * (size_t)n_out * H, st) != hipSuccess) return CSL_E_HIP;
+    hipLaunchKernelGGL(k_gat_bwd_t2, dim3((unsigned)b1), dim3(BLK), 0, st, t_indptr, t_indices, (long long)n_src,
+                       (long long)n_pad, el, er_out, z, (int)H, (int)D, slope, m_in, g_s, g_n, attn_l, g_er_out, g_z, scratch, r1);
+  }
+  if (b2 > 0) {
+    if (!attn_r || !aligned16(attn_r) || !self_ids_in) return CSL_E_INVALID;
+    hipLaunchKernelGGL(k_gat_logits_bwd_dst, dim3((unsigned)b2), dim3(BLK), 0, st, z, attn_r, self_ids_in, g_er_out,
+                       (long long)n_out, (int)H, (int)D, g_z, scratch + b1 * C, r2);
+  }
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch, b1, C, g_attn_l);
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch + b1 * C, b2, C, g_attn_r);
   return done();
 }
 
