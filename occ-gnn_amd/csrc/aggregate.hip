@@ -1219,9 +1219,9 @@ int csl_gat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, int64_t
   return done();
 }
 
-static long long gat_t_rows(long long n) {   // source rows per workgroup of k_gat_bwd_t2: at most ~4096 workgroups
-  long long r = 16;
-  while ((n + r - 1) / r > 4096) r *= 2;
+static long long gat_t_rows(long long n) {   // source rows per workgroup of k_gat_bwd_t2: at most ~1024 workgroups
+  long long r = 16;                        // (each leaves a row of partial sums for the second stage to read)
+  while ((n + r - 1) / r > 1024) r *= 2;
   return r;
 }
 
@@ -1255,9 +1255,14 @@ int csl_gat_bwd_t_fused_f32(const int32_t* t_indptr, const int32_t* t_indices, i
     hipLaunchKernelGGL(k_gat_logits_bwd_dst, dim3((unsigned)b2), dim3(BLK), 0, st, z, attn_r, self_ids_in, g_er_out,
                        (long long)n_out, (int)H, (int)D, g_z, scratch + b1 * C, r2);
   }
-  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch, b1, C, g_attn_l);
-  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 63) / 64)), dim3(BLK), 0, st, scratch + b1 * C, b2, C, g_attn_r);
-  return done();
+  {
+    // both second stages in one launch
+    const float* src[2] = {scratch, scratch + b1 * C};
+    const int64_t nb[2] = {b1, b2};
+    const int32_t hh[2] = {C, C};
+    float* dst[2] = {g_attn_l, g_attn_r};
+    return csl_reduce_multi_f32(2, src, nb, hh, dst, stream);
+  }
 }
 
 int csl_gat_finish_fwd_f32(const float* n_in, const float* s_in, const float* bias, int64_t n, int32_t H, int32_t D,
