@@ -161,13 +161,24 @@ int csl_sage_cat_rows_bwd_f32(const int32_t* self_ids, const int32_t* owned, con
  *   out[u, :] = mask_u .* sum over t in t_indices[t_indptr[u] .. t_indptr[u+1]) of
  *               ( t < 0 ? gcat[~t, 0:H) : gcat[t, H:2H) / max(indptr[t+1] - indptr[t], 1) ),   mask_u = y ? y[u, :] > 0 : 1
  * for u < n_src, zero rows up to n_pad; colsum[c] = sum_u out[u, c].  No atomics, nothing to pre-zero, deterministic.
- * indptr: the slice's CSR row pointers (the forward's mean divisors).  H % 4 == 0.
+ * indptr: the slice's CSR row pointers (the forward's mean divisors); NULL: no division (gcat's mean half is already
+ * divided: the rank step).  H % 4 == 0.
  * scratch: csl_sage_cat_bwd_t_scratch(n_pad, H) floats = [blocks][H] per-block column sums.  colsum == NULL: they are
  * left there for the caller's own second stage (csl_reduce_multi_f32 with nblk = scratch floats / H). */
 int64_t csl_sage_cat_bwd_t_scratch(int64_t n_pad, int32_t H);
 int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, const int32_t* indptr, const float* gcat,
                            int64_t ldg, const float* y, int64_t ldy, int64_t n_src, int64_t n_pad, float* out,
                            int64_t ldo, float* colsum, float* scratch, int32_t H, void* stream);
+
+/* Pieces of the split-parallel rank step's backward by source (csl_sage_rank_fwd_bwd_f32):
+ * csl_sage_rank_g2_f32: g2[owned[j], 0:H) = gcat[j, 0:H), g2[owned[j], H:2H) = gcat[j, H:2H) / max(deg[j], 1): the operand
+ * gradient from owned-row order into out-row order, the mean half divided by the TRUE degree (rows of other owners are
+ * filled from the reverse exchange with csl_scatter_rows_f32); csl_sage_cat_bwd_t_f32 with indptr = NULL then gathers
+ * over it without dividing again.  csl_scatter_rows_f32: dst[idx[k], 0:H) = src[k, 0:H), idx unique.  H % 4 == 0. */
+int csl_sage_rank_g2_f32(const int32_t* owned, const int32_t* deg, int64_t n_owned, const float* gcat, int64_t ldg, float* g2,
+                         int64_t ld2, int32_t H, void* stream);
+int csl_scatter_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t n, const float* src, int64_t lds, int32_t H,
+                         void* stream);
 
 /* The same where the slice by source has HUB lists (csl_layer_meta.t_max_len > CSL_T_SORTED_MAX: a node that thousands
  * of the minibatch's rows sampled; the reference's backward walks every edge with its own thread for the same reason,
@@ -342,6 +353,12 @@ typedef struct {
   const int32_t* from_all;
   const int32_t* to_all;
   int64_t n_out, n_in, n_owned, n_from, n_to;
+  /* optional (layers k >= 1): the part's slice by source (engine flag CSL_FLAG_TRANSPOSE with csl_config.part_mask): the
+   * backward then GATHERS the input gradient over it (csl_sage_rank_g2_f32 + csl_sage_cat_bwd_t_f32: no atomics, no zero
+   * fill, ReLU mask / padding / bias sums in the same pass) instead of scattering it; NULL: the atomic scatter form */
+  const int32_t* t_indptr;
+  const int32_t* t_indices;
+  int64_t t_max_len, t_entries;
 } csl_sage_rank_slice;
 typedef int (*csl_exchange_fn)(void* user, int32_t layer, int32_t backward, const float* src, float* dst, int32_t width,
                                void* stream);

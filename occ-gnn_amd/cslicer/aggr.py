@@ -24,7 +24,7 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_sage_rank_fwd_bwd_f32", "csl_sage_rank_workspace", "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch",
            "csl_gat_bwd_t_f32", "csl_sage_fwd_mfma_f32", "csl_sage_fwd_mfma_scratch", "csl_sage_step_timing",
            "csl_sage_step_timing_read", "csl_sage_cat_bwd_t_hub_f32", "csl_sage_cat_bwd_t_hub_scratch",
-           "csl_gat_bwd_t_fused_f32", "csl_gat_bwd_t_fused_scratch"]
+           "csl_gat_bwd_t_fused_f32", "csl_gat_bwd_t_fused_scratch", "csl_sage_rank_g2_f32", "csl_scatter_rows_f32"]
 _ready = False
 
 
@@ -79,6 +79,8 @@ def _lib():
         L.csl_gat_bwd_t_f32.argtypes = [vp, vp, i64, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]
         L.csl_gat_bwd_t_fused_f32.argtypes = [vp, vp, i64, i64, vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp, vp, i64, vp, vp,
                                               vp, vp, vp, vp]
+        L.csl_sage_rank_g2_f32.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp]
+        L.csl_scatter_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_gat_bwd_t_fused_scratch.argtypes = [i64, i64, i32, i32]
         L.csl_gat_bwd_t_fused_scratch.restype = i64
         L.csl_gat_finish_fwd_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]
@@ -458,7 +460,8 @@ class SageRankSlice(C.Structure):
     _fields_ = [("indptr", C.c_void_p), ("indices", C.c_void_p), ("self_ids_in", C.c_void_p),
                 ("owned_out_nodes", C.c_void_p), ("owned_degree", C.c_void_p), ("from_all", C.c_void_p),
                 ("to_all", C.c_void_p), ("n_out", C.c_int64), ("n_in", C.c_int64), ("n_owned", C.c_int64),
-                ("n_from", C.c_int64), ("n_to", C.c_int64)]
+                ("n_from", C.c_int64), ("n_to", C.c_int64), ("t_indptr", C.c_void_p), ("t_indices", C.c_void_p),
+                ("t_max_len", C.c_int64), ("t_entries", C.c_int64)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
@@ -549,6 +552,12 @@ class SageRankStep(object):
             c.from_all, c.to_all = s.ptr(A.FROM_IDS), s.ptr(A.TO_IDS)
             c.n_out, c.n_in, c.n_owned = s.n_out, s.n_in, s.n_owned
             c.n_from, c.n_to = sum(s.from_counts), sum(s.to_counts)
+            # the part's slice by source, where the engine emitted it (FLAG_TRANSPOSE): the backward gathers over it
+            if k and s.count(A.T_INDPTR) == s.n_in + 1 and s.n_in > 0:
+                c.t_indptr, c.t_indices = s.ptr(A.T_INDPTR), s.ptr(A.T_INDICES)
+                c.t_max_len, c.t_entries = s.t_max_len, s.count(A.T_INDICES)
+            else:
+                c.t_indptr, c.t_indices, c.t_max_len, c.t_entries = None, None, 0, 0
         L = _lib()
         need = L.csl_sage_rank_workspace(self.L, self._dims, self._sl, self.row_pad, self.n_slabs)
         if need < 0:

@@ -58,6 +58,11 @@ class Trainer(object):
         by_source = (not self.rank_path and self.P == 1 and model == "sage" and len(fanouts) > 1
                      and not os.environ.get("CSLICER_NO_TRANSPOSE"))
         eng_flags = _abi.FLAG_TRANSPOSE if by_source else 0
+        # one process per part, GraphSAGE, native rank step: the part's slices by source too (the backward gathers its input
+        # gradients over them instead of scattering them with atomics; CSLICER_NO_TRANSPOSE=1: A/B switch)
+        if (self.rank_path and model == "sage" and len(fanouts) > 1 and not os.environ.get("CSLICER_NO_TRANSPOSE")
+                and not os.environ.get("CSLICER_PY_STEP")):
+            eng_flags = _abi.FLAG_TRANSPOSE
         if (not self.rank_path and self.P == 1 and model == "gat" and not os.environ.get("CSLICER_NO_TRANSPOSE")):
             # GAT aggregates PROJECTED features: every layer's sources take a gradient, the deepest layer's too
             eng_flags = _abi.FLAG_TRANSPOSE | _abi.FLAG_TRANSPOSE_ALL

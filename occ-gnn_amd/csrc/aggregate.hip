@@ -736,7 +736,8 @@ __global__ __launch_bounds__(BLK) void k_sage_cat_bwd_t(const int* __restrict__ 
           const int ta = trow[j], tb = trow[j + 1];
           const int ra = ta < 0 ? ~ta : ta, rb = tb < 0 ? ~tb : tb;
           // (a self entry's divisor load is issued too and ignored: no branch between the loads)
-          const int da = indptr[ra + 1] - indptr[ra], db = indptr[rb + 1] - indptr[rb];
+          // (indptr == null: the caller's rows are already divided -- the split-parallel rank step)
+          const int da = indptr ? indptr[ra + 1] - indptr[ra] : 1, db = indptr ? indptr[rb + 1] - indptr[rb] : 1;
           const float4 va = *reinterpret_cast<const float4*>(gcat + (long long)ra * ldg + (ta < 0 ? 0 : H) + c);
           const float4 vb = *reinterpret_cast<const float4*>(gcat + (long long)rb * ldg + (tb < 0 ? 0 : H) + c);
           const float wa = ta < 0 ? 1.f : 1.f / (float)(da > 1 ? da : 1);
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(BLK) void k_sage_cat_bwd_t(const int* __restrict__ 
         if (j < j1) {
           const int ta = trow[j];
           const int ra = ta < 0 ? ~ta : ta;
-          const int da = indptr[ra + 1] - indptr[ra];
+          const int da = indptr ? indptr[ra + 1] - indptr[ra] : 1;
           const float4 va = *reinterpret_cast<const float4*>(gcat + (long long)ra * ldg + (ta < 0 ? 0 : H) + c);
           const float wa = ta < 0 ? 1.f : 1.f / (float)(da > 1 ? da : 1);
           acc.x += wa * va.x, acc.y += wa * va.y, acc.z += wa * va.z, acc.w += wa * va.w;
@@ -770,6 +771,45 @@ __host__ __device__ inline long long tb_rows(long long n_pad) {
   long long r = 64;
   while ((n_pad + r - 1) / r > 2048) r *= 2;
   return r;
+}
+
+// ---- the split-parallel rank step's backward by source (sage_step.hip, csl_sage_rank_fwd_bwd_f32).  The operand
+// gradient gcat [n_owned, 2H] is in OWNED-row order; the slice by source names OUT rows.  g2 [n_out, 2H] is the same in
+// out-row order with the mean half already divided by the TRUE degree (the forward's divisor: the merged sums of all
+// parts) -- G2[owned[j], 0:H) = gcat[j, 0:H), G2[owned[j], H:2H) = gcat[j, H:2H) / max(deg[j], 1); the mean halves of the
+// rows peers own arrive from the reverse exchange (k_scatter_rows_set) -- so that csl_sage_cat_bwd_t_f32 with
+// indptr = NULL gathers the input gradient over it: no atomics, no zero fill, ReLU mask + padding + bias sums in the pass.
+template <int G>
+__global__ __launch_bounds__(BLK) void k_rank_g2(const int* __restrict__ owned, const int* __restrict__ deg, long long n,
+                                                 const float* __restrict__ gcat, long long ldg, float* __restrict__ g2,
+                                                 long long ld2, int H) {
+  constexpr int RPB = BLK / G;
+  const int lane = threadIdx.x % G;
+  const long long j = (long long)blockIdx.x * RPB + threadIdx.x / G;
+  if (j >= n) return;
+  const long long o = owned[j];
+  const int d = deg[j];
+  const float inv = 1.0f / (float)(d > 1 ? d : 1);
+  for (int c = lane * 4; c < H; c += G * 4) {
+    const float4 a = *reinterpret_cast<const float4*>(gcat + j * ldg + c);
+    float4 m = *reinterpret_cast<const float4*>(gcat + j * ldg + H + c);
+    m.x *= inv, m.y *= inv, m.z *= inv, m.w *= inv;
+    *reinterpret_cast<float4*>(g2 + o * ld2 + c) = a;
+    *reinterpret_cast<float4*>(g2 + o * ld2 + H + c) = m;
+  }
+}
+
+// dst[idx[k], 0:H) = src[k, 0:H)   (idx unique)
+template <int G>
+__global__ __launch_bounds__(BLK) void k_scatter_rows_set(float* __restrict__ dst, long long ldd, const int* __restrict__ idx,
+                                                          long long n, const float* __restrict__ src, long long lds, int H) {
+  constexpr int RPB = BLK / G;
+  const int lane = threadIdx.x % G;
+  const long long k = (long long)blockIdx.x * RPB + threadIdx.x / G;
+  if (k >= n) return;
+  const long long o = idx[k];
+  for (int c = lane * 4; c < H; c += G * 4)
+    *reinterpret_cast<float4*>(dst + o * ldd + c) = *reinterpret_cast<const float4*>(src + k * lds + c);
 }
 
 // ---- hub lists.  A node that thousands of the minibatch's rows sampled has a list of thousands of entries in the slice
@@ -821,7 +861,7 @@ __global__ __launch_bounds__(BLK) void k_sage_cat_bwd_t_hub(const int* __restric
         for (long long j = a0 + sub; j < a1; j += RPB) {
           const int t = trow[j];
           const int r = t < 0 ? ~t : t;
-          const int d = indptr[r + 1] - indptr[r];
+          const int d = indptr ? indptr[r + 1] - indptr[r] : 1;
           const float4 v = *reinterpret_cast<const float4*>(gcat + (long long)r * ldg + (t < 0 ? 0 : H) + c);
           const float w = t < 0 ? 1.f : 1.f / (float)(d > 1 ? d : 1);
           acc.x += w * v.x, acc.y += w * v.y, acc.z += w * v.z, acc.w += w * v.w;
@@ -1434,7 +1474,7 @@ int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, co
   const long long blocks = (n_pad + rpb - 1) / rpb;
   if (blocks > 0) {
     if (!out || !scratch || ldo < H || ldo % 4 != 0 || !aligned16(out)) return CSL_E_INVALID;
-    if (n_src > 0 && (!t_indptr || !t_indices || !indptr || !gcat || ldg < 2 * (int64_t)H || ldg % 4 != 0 || !aligned16(gcat)))
+    if (n_src > 0 && (!t_indptr || !t_indices || !gcat || ldg < 2 * (int64_t)H || ldg % 4 != 0 || !aligned16(gcat)))
       return CSL_E_INVALID;
     if (y && (ldy < H || ldy % 4 != 0 || !aligned16(y))) return CSL_E_INVALID;
 #define LAUNCH_BWD_T(G)                                                                                           \
@@ -1448,6 +1488,30 @@ int csl_sage_cat_bwd_t_f32(const int32_t* t_indptr, const int32_t* t_indices, co
   }
   // colsum == NULL: the per-block sums stay in scratch[blocks][H] for the caller's own second stage (csl_reduce_multi_f32)
   if (colsum) hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((H + 63) / 64)), dim3(BLK), 0, st, scratch, blocks, (int)H, colsum);
+  return done();
+}
+
+int csl_sage_rank_g2_f32(const int32_t* owned, const int32_t* deg, int64_t n_owned, const float* gcat, int64_t ldg, float* g2,
+                         int64_t ld2, int32_t H, void* stream) {
+  if (n_owned == 0) return CSL_OK;
+  if (n_owned < 0 || H < 4 || H % 4 != 0 || !owned || !deg || !gcat || !g2 || ldg < 2 * (int64_t)H || ld2 < 2 * (int64_t)H ||
+      ldg % 4 != 0 || ld2 % 4 != 0 || !aligned16(gcat) || !aligned16(g2))
+    return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int G = group_for(H);
+  DISPATCH_G(G, k_rank_g2, n_owned, owned, deg, (long long)n_owned, gcat, (long long)ldg, g2, (long long)ld2, (int)H);
+  return done();
+}
+
+int csl_scatter_rows_f32(float* dst, int64_t ldd, const int32_t* idx, int64_t n, const float* src, int64_t lds, int32_t H,
+                         void* stream) {
+  if (n == 0) return CSL_OK;
+  if (n < 0 || H < 4 || H % 4 != 0 || !dst || !idx || !src || ldd < H || lds < H || ldd % 4 != 0 || lds % 4 != 0 ||
+      !aligned16(dst) || !aligned16(src))
+    return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int G = group_for(H);
+  DISPATCH_G(G, k_scatter_rows_set, n, dst, (long long)ldd, idx, (long long)n, src, (long long)lds, (int)H);
   return done();
 }
 
@@ -1466,7 +1530,7 @@ int csl_sage_cat_bwd_t_hub_f32(const int32_t* t_indptr, const int32_t* t_indices
   const long long blocks = (n_pad + rpb - 1) / rpb;
   if (blocks > 0) {
     if (!out || !scratch || ldo < H || ldo % 4 != 0 || !aligned16(out)) return CSL_E_INVALID;
-    if (n_src > 0 && (!t_indptr || !t_indices || !indptr || !gcat || ldg < 2 * (int64_t)H || ldg % 4 != 0 || !aligned16(gcat)))
+    if (n_src > 0 && (!t_indptr || !t_indices || !gcat || ldg < 2 * (int64_t)H || ldg % 4 != 0 || !aligned16(gcat)))
       return CSL_E_INVALID;
     if (y && (ldy < H || ldy % 4 != 0 || !aligned16(y))) return CSL_E_INVALID;
     const int thr = CSL_T_SORTED_MAX;

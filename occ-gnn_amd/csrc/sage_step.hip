@@ -327,7 +327,7 @@ namespace {
 
 struct RankLayout {
   int64_t x0, send[CSL_MAX_LAYERS], recv[CSL_MAX_LAYERS], agg[CSL_MAX_LAYERS], cat[CSL_MAX_LAYERS], y[CSL_MAX_LAYERS],
-      gy[CSL_MAX_LAYERS], gcat[CSL_MAX_LAYERS], gx[CSL_MAX_LAYERS], slabs[CSL_MAX_LAYERS], bpart[CSL_MAX_LAYERS],
+      gy[CSL_MAX_LAYERS], gcat[CSL_MAX_LAYERS], gx[CSL_MAX_LAYERS], g2[CSL_MAX_LAYERS], slabs[CSL_MAX_LAYERS], bpart[CSL_MAX_LAYERS],
       bblocks[CSL_MAX_LAYERS], mp[CSL_MAX_LAYERS];
   bool slabbed[CSL_MAX_LAYERS];
   int64_t lpart, lblocks, total;
@@ -353,11 +353,17 @@ bool rank_lay_out(int32_t L, const int32_t* dims, const csl_sage_rank_slice* sl,
     o.y[k] = at, at += up4(mp * out);
     o.gy[k] = at, at += up4(mp * out);
     o.gcat[k] = at, at += up4(mp * 2 * in);
-    o.gx[k] = at, at += k > 0 ? up4(s.n_in * in) : 0;
+    const bool by_src = k > 0 && s.t_indptr && s.t_indices;      // this layer's input gradient is gathered by source
+    o.gx[k] = at, at += (k > 0 && !by_src) ? up4(s.n_in * in) : 0;
+    o.g2[k] = at, at += by_src ? up4(s.n_out * 2 * in) : 0;
     const int64_t wn = out * 2 * in;
     o.slabbed[k] = row_pad > 0 && mp >= row_pad && n_slabs > 1 && mp % n_slabs == 0 && wn % 4 == 0;
     o.slabs[k] = at, at += o.slabbed[k] ? up4(wn * n_slabs) : 0;
-    const int64_t part = k + 1 < L ? csl_relu_bwd_colsum_scratch(mp, (int32_t)out) : 0;
+    // gb_k's first stage is written by layer k+1's backward: the mask pass behind the atomic scatter, or the gather by source
+    const bool src_above = k + 1 < L && sl[k + 1].t_indptr && sl[k + 1].t_indices;
+    const int64_t part = k + 1 < L ? (!src_above ? csl_relu_bwd_colsum_scratch(mp, (int32_t)out)
+                                     : sl[k + 1].t_max_len > CSL_T_SORTED_MAX ? csl_sage_cat_bwd_t_hub_scratch(mp, (int32_t)out)
+                                                                              : csl_sage_cat_bwd_t_scratch(mp, (int32_t)out)) : 0;
     o.bblocks[k] = part / out;
     o.bpart[k] = at, at += up4(part);
   }
@@ -490,6 +496,29 @@ int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_s
     if (k == 0) break;   // (no gradient flows into the input features; the deepest layer's exchange has no backward)
     STEP(csl_gemm_f32(0, 0, mp, 2 * (int64_t)in, out, ws + o.gy[k], out, 0, weights[k], 2 * (int64_t)in, 0, ws + o.gcat[k],
                       2 * (int64_t)in, 0, 1, nullptr, 0, stream));
+    if (s.t_indptr && s.t_indices) {
+      // BY SOURCE: the operand gradient goes into out-row order (mean half / true degree), the rows peers own get theirs
+      // from the reverse exchange, and ONE gather over the part's slice by source writes the input gradient with the ReLU
+      // mask of the layer below, its padding and its bias sums -- no atomics, no zero fill
+      float* g2 = ws + o.g2[k];
+      STEP(csl_sage_rank_g2_f32(s.owned_out_nodes, s.owned_degree, s.n_owned, ws + o.gcat[k], 2 * (int64_t)in, g2, 2 * (int64_t)in,
+                                in, stream));
+      // what this part received forward gets its gradient back (the mean halves of the owned rows it was merged into)
+      STEP(csl_gather_rows_f32(g2 + in, 2 * (int64_t)in, s.to_all, s.n_to, ws + o.recv[k], in, in, stream));
+      XCHG(k, 1, ws + o.recv[k], ws + o.send[k], in);
+      XWAIT(k, 1);
+      STEP(csl_scatter_rows_f32(g2 + in, 2 * (int64_t)in, s.from_all, s.n_from, ws + o.send[k], in, in, stream));
+      if (o.mp[k - 1] > 0) {
+        if (s.t_max_len > CSL_T_SORTED_MAX)
+          STEP(csl_sage_cat_bwd_t_hub_f32(s.t_indptr, s.t_indices, s.t_entries, nullptr, g2, 2 * (int64_t)in, ws + o.y[k - 1], in,
+                                          s.n_in, o.mp[k - 1], ws + o.gy[k - 1], in, nullptr, ws + o.bpart[k - 1], in, stream));
+        else
+          STEP(csl_sage_cat_bwd_t_f32(s.t_indptr, s.t_indices, nullptr, g2, 2 * (int64_t)in, ws + o.y[k - 1], in, s.n_in,
+                                      o.mp[k - 1], ws + o.gy[k - 1], in, nullptr, ws + o.bpart[k - 1], in, stream));
+      }
+      defer(ws + o.bpart[k - 1], o.mp[k - 1] > 0 ? o.bblocks[k - 1] : 0, in, gb[k - 1]);
+      continue;
+    }
     // operand gradient -> self rows of gx and owned rows of the merged sums' gradient (both zeroed inside)
     STEP(csl_sage_cat_rows_bwd_f32(s.self_ids_in, s.owned_out_nodes, s.owned_degree, s.n_owned, ws + o.gcat[k],
                                    2 * (int64_t)in, ws + o.gx[k], s.n_in, ws + o.agg[k], s.n_out, in, stream));
