@@ -37,6 +37,12 @@ int csl_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const int32_
 int csl_spmm_sum_compact_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
                              const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, void* stream);
 
+/* csl_spmm_sum_f32 / _compact_f32 (compact != 0) over a RESIDENT table: the source row of index s is x[rowmap[s]] (rowmap
+ * NULL: x[s]).  The deepest layer of a rank reads its feature rows in place (python/data/bipartite.py:61-67 on the
+ * owner's feature shard) instead of gathering them into an input matrix first. */
+int csl_spmm_sum_map_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows, const float* x,
+                         int64_t ldx, const int32_t* rowmap, float* out, int64_t ldo, int32_t H, int32_t compact, void* stream);
+
 /* grad_x[indices[e], :] += grad_out[q, :] for every edge e of row = rows ? rows[r] : r,
  * r in [0, n_rows); q = compact ? r : row (compact: grad_out holds only the listed rows). fp32 atomics. */
 int csl_spmm_sum_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,

@@ -24,7 +24,7 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_sage_rank_fwd_bwd_f32", "csl_sage_rank_workspace", "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch",
            "csl_gat_bwd_t_f32", "csl_sage_fwd_mfma_f32", "csl_sage_fwd_mfma_scratch", "csl_sage_step_timing",
            "csl_sage_step_timing_read", "csl_sage_cat_bwd_t_hub_f32", "csl_sage_cat_bwd_t_hub_scratch",
-           "csl_gat_bwd_t_fused_f32", "csl_gat_bwd_t_fused_scratch", "csl_sage_rank_g2_f32", "csl_scatter_rows_f32"]
+           "csl_gat_bwd_t_fused_f32", "csl_gat_bwd_t_fused_scratch", "csl_sage_rank_g2_f32", "csl_scatter_rows_f32", "csl_spmm_sum_map_f32"]
 _ready = False
 
 
@@ -81,6 +81,7 @@ def _lib():
                                               vp, vp, vp, vp]
         L.csl_sage_rank_g2_f32.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp]
         L.csl_scatter_rows_f32.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp]
+        L.csl_spmm_sum_map_f32.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, i64, i32, i32, vp]
         L.csl_gat_bwd_t_fused_scratch.argtypes = [i64, i64, i32, i32]
         L.csl_gat_bwd_t_fused_scratch.restype = i64
         L.csl_gat_finish_fwd_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, vp, vp]

@@ -51,7 +51,10 @@ __global__ __launch_bounds__(BLK) void k_spmm_sum(const int* __restrict__ indptr
                                                   const int* __restrict__ indices,
                                                   const int* __restrict__ rows, long long n_rows,
                                                   const float* __restrict__ x, long long ldx, float* __restrict__ out,
-                                                  long long ldo, int H, int vec_ok, int compact) {
+                                                  long long ldo, int H, int vec_ok, int compact,
+                                                  const int* __restrict__ rowmap) {
+  // rowmap: x is a resident table read through it (x row of source s = rowmap[s]): the deepest layer of a rank reads its
+  // feature rows in place instead of gathering them into an input matrix first
   constexpr int RPB = BLK / G;  // rows per block
   const int lane = threadIdx.x % G;
   const long long r = (long long)blockIdx.x * RPB + threadIdx.x / G;
@@ -64,7 +67,8 @@ __global__ __launch_bounds__(BLK) void k_spmm_sum(const int* __restrict__ indptr
     long long e = e0;
     // four source rows in flight per lane
     for (; e + 4 <= e1; e += 4) {
-      const long long s0 = indices[e], s1 = indices[e + 1], s2 = indices[e + 2], s3 = indices[e + 3];
+      long long s0 = indices[e], s1 = indices[e + 1], s2 = indices[e + 2], s3 = indices[e + 3];
+      if (rowmap) s0 = rowmap[s0], s1 = rowmap[s1], s2 = rowmap[s2], s3 = rowmap[s3];
       float4 v0, v1, v2, v3;
       if (vec_ok) {
         v0 = *reinterpret_cast<const float4*>(x + s0 * ldx + c);
@@ -84,7 +88,8 @@ __global__ __launch_bounds__(BLK) void k_spmm_sum(const int* __restrict__ indptr
       add4(acc, v3);
     }
     for (; e < e1; e++) {
-      const long long s0 = indices[e];
+      long long s0 = indices[e];
+      if (rowmap) s0 = rowmap[s0];
       add4(acc, vec_ok ? *reinterpret_cast<const float4*>(x + s0 * ldx + c) : ld4(x + s0 * ldx, c, H));
     }
     if (vec_ok) {
@@ -1224,14 +1229,20 @@ int done() { return hipGetLastError() == hipSuccess ? CSL_OK : CSL_E_HIP; }
 extern "C" {
 
 static int spmm_sum_impl(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,
-                         const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, int compact, void* stream) {
+                         const float* x, int64_t ldx, float* out, int64_t ldo, int32_t H, int compact, void* stream,
+                         const int32_t* rowmap = nullptr) {
   if (n_rows == 0) return CSL_OK;  // nothing to do: empty lists come with null pointers
   if (n_rows < 0 || H < 1 || !indptr || !out || ldx < H || ldo < H || (compact && !rows)) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int G = group_for(H), v = vec_ok(x, ldx, out, ldo, H);
   DISPATCH_G(G, k_spmm_sum, n_rows, indptr, indices, rows,
-             (long long)n_rows, x, (long long)ldx, out, (long long)ldo, (int)H, v, compact);
+             (long long)n_rows, x, (long long)ldx, out, (long long)ldo, (int)H, v, compact, rowmap);
   return done();
+}
+
+int csl_spmm_sum_map_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows, const float* x,
+                         int64_t ldx, const int32_t* rowmap, float* out, int64_t ldo, int32_t H, int32_t compact, void* stream) {
+  return spmm_sum_impl(indptr, indices, rows, n_rows, x, ldx, out, ldo, H, compact ? 1 : 0, stream, rowmap);
 }
 
 int csl_spmm_sum_f32(const int32_t* indptr, const int32_t* indices, const int32_t* rows, int64_t n_rows,

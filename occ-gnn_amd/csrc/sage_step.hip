@@ -331,13 +331,14 @@ struct RankLayout {
       bblocks[CSL_MAX_LAYERS], mp[CSL_MAX_LAYERS];
   bool slabbed[CSL_MAX_LAYERS];
   int64_t lpart, lblocks, total;
+  int64_t wpack;   // W_0 in MFMA operand order when the deepest layer has no boundary rows on this part (else -1)
 };
 
 bool rank_lay_out(int32_t L, const int32_t* dims, const csl_sage_rank_slice* sl, int64_t row_pad, int32_t n_slabs,
                   RankLayout& o) {
   if (L < 1 || L > CSL_MAX_LAYERS || n_slabs < 1) return false;
   int64_t at = 0;
-  o.x0 = at, at += up4(sl[0].n_in * (int64_t)dims[0]);
+  o.x0 = 0;   // (the deepest layer reads the resident feature rows through feat_rows: no gathered input matrix)
   for (int k = 0; k < L; k++) {
     const int64_t in = dims[k], out = dims[k + 1];
     const csl_sage_rank_slice& s = sl[k];
@@ -373,6 +374,15 @@ bool rank_lay_out(int32_t L, const int32_t* dims, const csl_sage_rank_slice* sl,
   o.lpart = at, at += up4(o.lblocks);
   o.bblocks[L - 1] = o.lblocks;
   o.bpart[L - 1] = at, at += up4(o.lblocks * C);
+  {
+    // a deepest layer WITHOUT boundary rows on this part (every out row owned, nothing sent or received: a world of one,
+    // or a partition that keeps a minibatch's neighbourhoods local) is the single-GPU layer: one fused kernel
+    const csl_sage_rank_slice& s0 = sl[0];
+    const bool local = s0.n_from == 0 && s0.n_to == 0 && s0.n_owned == s0.n_out && !getenv("CSLICER_NO_MFMA_FWD");
+    const int64_t wp = local ? csl_sage_fwd_mfma_scratch(dims[0], dims[1]) : -1;
+    o.wpack = wp > 0 ? at : -1;
+    if (wp > 0) at += up4(wp);
+  }
   o.total = at;
   return true;
 }
@@ -440,19 +450,28 @@ int csl_sage_rank_fwd_bwd_f32(int32_t n_layers, const int32_t* dims, const csl_s
     }                                                                                              \
   } while (0)
   // ---- forward
-  k = 0;
-  STEP(csl_gather_rows_f32(feat, ldf, feat_rows, sl[0].n_in, ws + o.x0, dims[0], dims[0], stream));
   for (k = 0; k < L; k++) {
     const int32_t in = dims[k], out = dims[k + 1];
     const csl_sage_rank_slice& s = sl[k];
-    const float* x = k == 0 ? ws + o.x0 : ws + o.y[k - 1];
+    // the deepest layer reads the resident feature rows through feat_rows (no gathered input matrix)
+    const float* x = k == 0 ? feat : ws + o.y[k - 1];
+    const int64_t ldx = k == 0 ? ldf : (int64_t)in;
+    const int32_t* map = k == 0 ? feat_rows : nullptr;
+    if (k == 0 && o.wpack >= 0) {
+      // no boundary rows: the single-GPU layer as one kernel (gather -> fp32 MFMA -> bias + ReLU); the CSR degree IS the
+      // true degree, the owned rows ARE the out rows
+      STEP(csl_sage_fwd_mfma_f32(s.indptr, s.indices, s.self_ids_in, feat_rows, feat, ldf, weights[0], 2 * (int64_t)in,
+                                 biases[0], s.n_owned, o.mp[0], in, out, 0, L > 1 ? 1 : 0, ws + o.cat[0], 2 * (int64_t)in,
+                                 ws + o.y[0], out, ws + o.wpack, stream));
+      continue;
+    }
     // partial sums of the rows peers own, straight into the send buffer; then the rows this part owns
-    STEP(csl_spmm_sum_compact_f32(s.indptr, s.indices, s.from_all, s.n_from, x, in, ws + o.send[k], in, in, stream));
+    STEP(csl_spmm_sum_map_f32(s.indptr, s.indices, s.from_all, s.n_from, x, ldx, map, ws + o.send[k], in, in, 1, stream));
     XCHG(k, 0, ws + o.send[k], ws + o.recv[k], in);
-    STEP(csl_spmm_sum_f32(s.indptr, s.indices, s.owned_out_nodes, s.n_owned, x, in, ws + o.agg[k], in, in, stream));
+    STEP(csl_spmm_sum_map_f32(s.indptr, s.indices, s.owned_out_nodes, s.n_owned, x, ldx, map, ws + o.agg[k], in, in, 0, stream));
     XWAIT(k, 0);
     STEP(csl_scatter_add_rows_atomic_f32(ws + o.agg[k], in, s.to_all, s.n_to, ws + o.recv[k], in, in, stream));
-    STEP(csl_sage_cat_f32(nullptr, nullptr, s.self_ids_in, s.owned_out_nodes, s.owned_degree, nullptr, x, in, ws + o.agg[k],
+    STEP(csl_sage_cat_f32(nullptr, nullptr, s.self_ids_in, s.owned_out_nodes, s.owned_degree, map, x, ldx, ws + o.agg[k],
                           in, s.n_owned, o.mp[k], ws + o.cat[k], 2 * (int64_t)in, in, 0, stream));
     STEP(csl_gemm_f32(0, 1, o.mp[k], out, 2 * (int64_t)in, ws + o.cat[k], 2 * (int64_t)in, 0, weights[k], 2 * (int64_t)in, 0,
                       ws + o.y[k], out, 0, 1, biases[k], k + 1 < L ? 1 : 0, stream));
