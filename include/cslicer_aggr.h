@@ -102,6 +102,38 @@ int csl_gat_bwd_t_fused_f32(const int32_t* t_indptr, const int32_t* t_indices, i
                             const int32_t* self_ids_in, int64_t n_out, float* g_er_out, float* g_z, float* g_attn_l,
                             float* g_attn_r, float* scratch, void* stream);
 
+/* ---- the attention model's INPUT layer, aggregate-then-project (csrc/gat_input.hip) ----
+ * DistGATConv on a layer whose input takes no gradient (the feature table): logits and weighted sum are linear in x, so
+ *   v_l[h] = W_h^T attn_l[h], v_r likewise [H, F];  el[u, h] = <x[u], v_l[h]>;  er[v, h] = <x[v], v_r[h]>
+ *   alpha_h(u -> v) = softmax over the sampled in-edges of v of LeakyReLU(el[u, h] + er[v, h])
+ *   agg[v, h, :] = sum_u alpha_h(u -> v) x[u]           (then out[v, h, :] = W_h agg[v, h, :] + bias: a batched csl_gemm_f32)
+ * give the same layer without projecting the sources (python/data/bipartite.py:75-80 is the reference's only piece of it).
+ * csl_gat_in_fwd_f32: agg [n_out, H * F] and alpha [n_edges, H] (kept for the backward; its sign bit = the logit was <= 0)
+ * from the slice's CSR (indptr [n_out + 1], indices [n_edges], self_ids [n_out]: the destination's own source row or -1)
+ * over x read through rowmap (source s = row rowmap[s] of x; NULL: row s).  H in {1, 2, 4, 8}; F % 4 == 0, F <= 128;
+ * every row has at most max_deg <= csl_gat_in_max_degree() = 32 edges (the slicer's fanout; the kernel instance is chosen by
+ * it and keeps a row's feature rows in registers; longer rows would be CUT, so the caller must not pass them); x / v_l / v_r / agg 16-byte aligned, ldx % 4 == 0.
+ * csl_gat_in_bwd_f32: g_vl, g_vr [H, F] from dagg (the gradient of agg; element [r, h, f] at r * ld_r + h * ld_h + f):
+ *   dalpha = <dagg[r, h], x[u]>;  dlogit = alpha (dalpha - sum_e alpha dalpha) * LeakyReLU';
+ *   g_vl[h] = sum_e dlogit x[u_e];  g_vr[h] = sum_r (sum_e dlogit) x[self(r)]     (two-stage sums, no atomics).
+ * scratch: csl_gat_in_bwd_scratch(n_out, H, F) floats. */
+int32_t csl_gat_in_max_degree(void);
+int csl_gat_in_fwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
+                       const float* x, int64_t ldx, int32_t F, const float* vl, const float* vr, int32_t H, float slope,
+                       int64_t n_out, int64_t n_edges, int32_t max_deg, float* agg, float* alpha, void* stream);
+int64_t csl_gat_in_bwd_scratch(int64_t n_out, int32_t H, int32_t F);
+int csl_gat_in_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
+                       const float* x, int64_t ldx, int32_t F, const float* alpha, const float* dagg, int64_t ld_r,
+                       int64_t ld_h, int32_t H, float slope, int64_t n_out, int64_t n_edges, int32_t max_deg, float* g_vl,
+                       float* g_vr, float* scratch, void* stream);
+/* y[r, 0:C) = act(y[r, 0:C) + bias) in place for r < n (act = ELU, alpha 1, when elu != 0; C % 4 == 0), and its
+ * backward: out[r, :] = g[r, :] * act'(y[r, :]) (from the activation's OUTPUT: y > 0 ? 1 : y + 1), colsum[C] = the
+ * column sums of out (the bias gradient; two-stage).  C <= 256; scratch: csl_elu_bwd_colsum_scratch(n, C) floats. */
+int csl_bias_elu_f32(float* y, int64_t ldy, const float* bias, int64_t n, int32_t C, int32_t elu, void* stream);
+int64_t csl_elu_bwd_colsum_scratch(int64_t n, int32_t C);
+int csl_elu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t n, int32_t C, int32_t elu,
+                           float* out, int64_t ldo, float* colsum, float* scratch, void* stream);
+
 /* GAT attention logits (DistGATConv.project): el[r, h] = <z[r, h, :], attn_l[h, :]>, er likewise; z [n, H*D],
  * attn_* [H, D], el/er [n, H]; D % 4 == 0, D <= 256, 16-byte aligned.  Backward: g_z [n, H*D] is WRITTEN
  * (g_el a_l + g_er a_r), g_attn_l / g_attn_r [H, D] are the sums over the rows (two-stage, no atomics);

@@ -24,7 +24,9 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_sage_rank_fwd_bwd_f32", "csl_sage_rank_workspace", "csl_gat_logits_bwd_acc_f32", "csl_gat_finish_fwd_f32", "csl_gat_finish_bwd_f32", "csl_gat_finish_bwd_scratch",
            "csl_gat_bwd_t_f32", "csl_sage_fwd_mfma_f32", "csl_sage_fwd_mfma_scratch", "csl_sage_step_timing",
            "csl_sage_step_timing_read", "csl_sage_cat_bwd_t_hub_f32", "csl_sage_cat_bwd_t_hub_scratch",
-           "csl_gat_bwd_t_fused_f32", "csl_gat_bwd_t_fused_scratch", "csl_sage_rank_g2_f32", "csl_scatter_rows_f32", "csl_spmm_sum_map_f32"]
+           "csl_gat_bwd_t_fused_f32", "csl_gat_bwd_t_fused_scratch", "csl_sage_rank_g2_f32", "csl_scatter_rows_f32", "csl_spmm_sum_map_f32",
+           "csl_gat_in_max_degree", "csl_gat_in_fwd_f32", "csl_gat_in_bwd_scratch", "csl_gat_in_bwd_f32", "csl_bias_elu_f32",
+           "csl_elu_bwd_colsum_scratch", "csl_elu_bwd_colsum_f32"]
 _ready = False
 
 
@@ -95,6 +97,14 @@ def _lib():
         L.csl_sage_fwd_mfma_scratch.restype = i64
         L.csl_sage_fwd_mfma_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, vp, i64,
                                             vp, i64, vp, vp]
+        L.csl_gat_in_fwd_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, i32, f32, i64, i64, i32, vp, vp, vp]
+        L.csl_gat_in_bwd_scratch.argtypes = [i64, i32, i32]
+        L.csl_gat_in_bwd_scratch.restype = i64
+        L.csl_gat_in_bwd_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i64, i32, f32, i64, i64, i32, vp, vp, vp, vp]
+        L.csl_bias_elu_f32.argtypes = [vp, i64, vp, i64, i32, i32, vp]
+        L.csl_elu_bwd_colsum_scratch.argtypes = [i64, i32]
+        L.csl_elu_bwd_colsum_scratch.restype = i64
+        L.csl_elu_bwd_colsum_f32.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp, vp, vp]
         _ready = True
     return L
 
@@ -873,6 +883,101 @@ class GatLayerLocal(torch.autograd.Function):
             if gx.shape[0] != ctx.x_rows:
                 gx = gx[:ctx.x_rows]
         return gx, gw, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None, None, None, None
+
+
+class FeatureRows(object):
+    """The input of the deepest layer as (resident feature table, rows): row s of the layer's input is
+    table[rows[s]] (rows = the slice's in_nodes).  A layer that can read its input through the map (GatInputLayer)
+    takes this instead of a gathered matrix."""
+    __slots__ = ("table", "rows")
+
+    def __init__(self, table, rows):
+        self.table, self.rows = table, rows
+
+
+def gat_input_ok(H, F, fanout):
+    """whether GatInputLayer covers a layer of H heads on F input features whose rows have <= fanout edges"""
+    return H in (1, 2, 4, 8) and F % 4 == 0 and 4 <= F <= 128 and 0 < fanout <= int(_lib().csl_gat_in_max_degree())
+
+
+def _gemm_batched(transa, transb, m, n, k, a, lda, sa, b, ldb, sb, c, ldc, sc, batch):
+    L = _lib()
+    rc = L.csl_gemm_f32(int(transa), int(transb), m, n, k, _p(a), lda, sa, _p(b), ldb, sb, _p(c), ldc, sc, batch,
+                        C.c_void_p(0), 0, _stream())
+    if rc < 0:
+        raise _abi.CslError(rc, "csl_gemm_f32: " + L.csl_gemm_last_error().decode())
+
+
+class GatInputLayer(torch.autograd.Function):
+    """A DistGATConv layer (+ ELU) of a single part whose input is the FEATURE TABLE (no input gradient), as
+    aggregate-then-project (csrc/gat_input.hip): the attention logits and the weighted sum are linear in x, so
+        v_l = W_h^T a_l, v_r = W_h^T a_r;  agg[v, h] = sum_u alpha_h(u -> v) x[u]  (csl_gat_in_fwd_f32, raw rows through
+        `rows`);  out[v, h] = W_h agg[v, h] + bias  (H GEMMs over the n_out DESTINATIONS, one batched csl_gemm_f32)
+    equals GatLayerLocal on the gathered rows up to fp32 rounding, with a tenth of its flops and without the projected
+    source matrix, the gathered input matrix or the layer's slice by source.  Backward: dW_h = g_h^T agg_h, dagg_h = g_h W_h
+    (batched GEMMs), one pass over the edges for the gradients of v_l / v_r (csl_gat_in_bwd_f32), then the chain rule
+    through v = W^T a."""
+
+    @staticmethod
+    def forward(ctx, table, rows, weight, attn_l, attn_r, bias, indptr, indices, self_ids_in, n_out, n_edges, max_deg, slope,
+                elu, row_pad, pad_out):
+        """max_deg: no row of the CSR has more edges (the slicer's fanout of the layer)"""
+        H, D = attn_l.shape
+        F, Cw = table.shape[1], H * D
+        table, weight = _f32(table), _f32(weight).contiguous()
+        al, ar, b = _f32(attn_l).contiguous(), _f32(attn_r).contiguous(), _f32(bias).contiguous()
+        indptr, indices, self_ids_in = _i32(indptr), _i32(indices), _i32(self_ids_in)
+        rows = _i32(rows) if rows is not None else None
+        dev = table.device
+        L = _lib()
+        Wv = weight.view(H, D, F)
+        vl = torch.einsum("hdf,hd->hf", Wv, al).contiguous()
+        vr = torch.einsum("hdf,hd->hf", Wv, ar).contiguous()
+        agg = torch.empty((n_out, H * F), dtype=torch.float32, device=dev)
+        alpha = torch.empty((max(n_edges, 1), H), dtype=torch.float32, device=dev)
+        _chk(L.csl_gat_in_fwd_f32(_p(indptr), _p(indices), _p(self_ids_in), _p(rows), _p(table), table.stride(0), F, _p(vl),
+                                  _p(vr), H, slope, n_out, n_edges, max_deg, _p(agg), _p(alpha), _stream()), "csl_gat_in_fwd_f32")
+        out = padded_rows(n_out, Cw, row_pad, dev).t if pad_out else torch.empty((n_out, Cw), dtype=torch.float32,
+                                                                                  device=dev)
+        if n_out:
+            # out[:, h*D:(h+1)*D] = agg[:, h*F:(h+1)*F] @ W_h^T: the H matrices interleaved in agg / out rows
+            _gemm_batched(0, 1, n_out, D, F, agg, H * F, F, weight, F, D * F, out, Cw, D, H)
+            _chk(L.csl_bias_elu_f32(_p(out), Cw, _p(b), n_out, Cw, 1 if elu else 0, _stream()), "csl_bias_elu_f32")
+        ctx.save_for_backward(table, rows, weight, al, ar, agg, alpha, out, indptr, indices, self_ids_in)
+        ctx.cfg = (n_out, n_edges, max_deg, H, D, F, slope, bool(elu))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        table, rows, weight, al, ar, agg, alpha, out, indptr, indices, self_ids_in = ctx.saved_tensors
+        n_out, n_edges, max_deg, H, D, F, slope, elu = ctx.cfg
+        Cw, dev = H * D, table.device
+        L = _lib()
+        g = _f32(g)
+        if g.stride(-1) != 1 or g.stride(0) % 4:
+            g = g.contiguous()
+        gg = torch.empty((n_out, Cw), dtype=torch.float32, device=dev)
+        g_bias = torch.empty((Cw,), dtype=torch.float32, device=dev)
+        buf = torch.empty((max(int(L.csl_elu_bwd_colsum_scratch(n_out, Cw)), int(L.csl_gat_in_bwd_scratch(n_out, H, F)), 4),),
+                          dtype=torch.float32, device=dev)
+        _chk(L.csl_elu_bwd_colsum_f32(_p(g), g.stride(0), _p(out), Cw, n_out, Cw, 1 if elu else 0, _p(gg), Cw, _p(g_bias),
+                                      _p(buf), _stream()), "csl_elu_bwd_colsum_f32")
+        gW = torch.zeros((H, D, F), dtype=torch.float32, device=dev) if not n_out else torch.empty(
+            (H, D, F), dtype=torch.float32, device=dev)
+        dagg = torch.empty((n_out, H * F), dtype=torch.float32, device=dev)
+        g_v = torch.empty((2, H, F), dtype=torch.float32, device=dev)
+        if n_out:
+            # dW_h = g_h^T agg_h  [D, F] (the sum runs over the n_out rows);  dagg_h = g_h W_h  [n_out, F]
+            _gemm_batched(1, 0, D, F, n_out, gg, Cw, D, agg, H * F, F, gW, F, D * F, H)
+            _gemm_batched(0, 0, n_out, F, D, gg, Cw, D, weight, F, D * F, dagg, H * F, F, H)
+        _chk(L.csl_gat_in_bwd_f32(_p(indptr), _p(indices), _p(self_ids_in), _p(rows), _p(table), table.stride(0), F, _p(alpha),
+                                  _p(dagg), H * F, F, H, slope, n_out, n_edges, max_deg, C.c_void_p(g_v[0].data_ptr()),
+                                  C.c_void_p(g_v[1].data_ptr()), _p(buf), _stream()), "csl_gat_in_bwd_f32")
+        # chain rule through v_l[h] = W_h^T a_l[h] (and v_r)
+        Wv = weight.view(H, D, F)
+        gW = gW + al.unsqueeze(2) * g_v[0].unsqueeze(1) + ar.unsqueeze(2) * g_v[1].unsqueeze(1)
+        g_a = torch.einsum("hdf,shf->shd", Wv, g_v)
+        return (None, None, gW.view(Cw, F), g_a[0], g_a[1], g_bias) + (None,) * 10
 
 
 def attention_gather(indptr, indices, u_in, v_in, n_rows):

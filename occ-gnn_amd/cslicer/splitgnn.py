@@ -59,7 +59,7 @@ class Slice(object):
     from_all / to_all: the per-peer lists back to back (receiver / sender order, the own one empty)."""
 
     __slots__ = ("part", "n_parts", "n_in", "n_out", "n_owned", "n_edges", "from_counts", "to_counts", "t_max_len",
-                 "_t", "_origin", "_lbase", "_lm") + \
+                 "fanout", "_t", "_origin", "_lbase", "_lm") + \
         tuple(_SLICE_LISTS) + ("from_ids", "to_ids")
 
     def _seg(self, kind, lo, hi):
@@ -138,6 +138,7 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
             s.from_counts = [int(lm.pair_off[0][g][p + 1]) - int(lm.pair_off[0][g][p]) for p in range(P)]
             s.to_counts = [int(lm.pair_off[1][g][p + 1]) - int(lm.pair_off[1][g][p]) for p in range(P)]
             s.t_max_len = int(lm.t_max_len[g])      # longest list of the slice by source (hubs: > _abi.T_SORTED_MAX)
+            s.fanout = eng.fanouts[l]               # no row of the slice's CSR is longer
             row[g] = s
         out.append(row)
     return out
@@ -145,6 +146,7 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
 
 import os as _os
 _NO_LOCAL_FUSE = bool(_os.environ.get("CSLICER_NO_LOCAL_FUSE"))   # A/B switch for the single-part fused layer
+_NO_GAT_INPUT = bool(_os.environ.get("CSLICER_GAT_NO_INPUT_LAYER"))  # A/B switch: the deepest GAT layer projects its sources
 ROW_PAD = 4096   # GEMM row counts are rounded up to a multiple of this (see DistSageConv.finish)
 SPLIT_K = 32     # the weight-gradient GEMM reduces over the rows in this many independent slabs
 
@@ -485,17 +487,28 @@ class DistGATConv(nn.Module):
         (fused single-part layer only): hand the output on as an aggr.PaddedRows."""
         parts = sorted(sl.keys())
         if len(parts) == 1 and sl[parts[0]].n_parts == 1 and not _NO_LOCAL_FUSE and (
-                isinstance(x[parts[0]], aggr.PaddedRows) or x[parts[0]].is_cuda):
+                isinstance(x[parts[0]], (aggr.PaddedRows, aggr.FeatureRows)) or x[parts[0]].is_cuda):
             # one part holding every node: the whole layer (+ ELU) as one autograd node.  The layers hand each other
             # row-padded buffers (aggr.PaddedRows), so that none copies its input into a padded GEMM operand again
             g = parts[0]
             xin = x[g]
+            if isinstance(xin, aggr.FeatureRows):
+                # the deepest layer on the resident feature table: aggregate the raw rows, project the destinations
+                if not _NO_GAT_INPUT and aggr.gat_input_ok(self.H, xin.table.shape[1], sl[g].fanout):
+                    out = aggr.GatInputLayer.apply(xin.table, xin.rows, self.fc.weight, self.attn_l, self.attn_r, self.bias,
+                                                   sl[g].indptr, sl[g].indices, sl[g].self_ids_in, sl[g].n_out,
+                                                   sl[g].n_edges, sl[g].fanout, self.slope, bool(elu), ROW_PAD, bool(pad_out))
+                    return {g: aggr.PaddedRows(out, sl[g].n_out) if pad_out else out}
+                xp = aggr.padded_rows(xin.rows.numel(), xin.table.shape[1], ROW_PAD, xin.table.device)
+                aggr.gather_rows(xin.table, xin.rows, out=xp.t[:xp.n])
+                xin = xp
             padded = isinstance(xin, aggr.PaddedRows)
             out = aggr.GatLayerLocal.apply(xin.t if padded else xin, self.fc.weight, self.attn_l, self.attn_r, self.bias,
                                            sl[g].indptr, sl[g].indices, sl[g].self_ids_in, sl[g].n_out, self.slope,
                                            bool(elu), ROW_PAD, _weight_grad, sl[g].t_indptr, sl[g].t_indices,
                                            sl[g].t_max_len, xin.n if padded else None, bool(pad_out))
             return {g: aggr.PaddedRows(out, sl[g].n_out) if pad_out else out}
+        x = {g: (aggr.gather_rows(v.table, v.rows) if isinstance(v, aggr.FeatureRows) else v) for g, v in x.items()}
         out = self._forward_parts(sl, {g: (v.t[:v.n] if isinstance(v, aggr.PaddedRows) else v) for g, v in x.items()})
         return {g: torch.nn.functional.elu(v) for g, v in out.items()} if elu else out
 
@@ -596,7 +609,7 @@ class DistGATModel(nn.Module):
         parts = sorted(slices[0].keys())
         x = {g: feats[g] for g in parts}
         fused = (len(parts) == 1 and slices[0][parts[0]].n_parts == 1 and not _NO_LOCAL_FUSE and
-                 (isinstance(x[parts[0]], aggr.PaddedRows) or x[parts[0]].is_cuda))
+                 (isinstance(x[parts[0]], (aggr.PaddedRows, aggr.FeatureRows)) or x[parts[0]].is_cuda))
         for k, conv in enumerate(self.convs):
             last = k + 1 == len(self.convs)
             x = conv.forward_parts(slices[L - 1 - k], x, elu=not last, pad_out=fused and not last)

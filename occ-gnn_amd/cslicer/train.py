@@ -64,8 +64,12 @@ class Trainer(object):
                 and not os.environ.get("CSLICER_PY_STEP")):
             eng_flags = _abi.FLAG_TRANSPOSE
         if (not self.rank_path and self.P == 1 and model == "gat" and not os.environ.get("CSLICER_NO_TRANSPOSE")):
-            # GAT aggregates PROJECTED features: every layer's sources take a gradient, the deepest layer's too
-            eng_flags = _abi.FLAG_TRANSPOSE | _abi.FLAG_TRANSPOSE_ALL
+            # GAT aggregates PROJECTED features: every layer's sources take a gradient -- the deepest layer's too, unless
+            # it runs aggregate-then-project on the raw feature rows (aggr.GatInputLayer: no source gradient at all)
+            F_in = features.shape[1] if feat_dim is None and not callable(features) else feat_dim
+            self.gat_input = (not splitgnn._NO_GAT_INPUT and not splitgnn._NO_LOCAL_FUSE and F_in is not None
+                              and aggr.gat_input_ok(heads, F_in, fanouts[-1]))
+            eng_flags = _abi.FLAG_TRANSPOSE | (0 if self.gat_input else _abi.FLAG_TRANSPOSE_ALL)
         self.eng = _abi.Engine(indptr, indices, n_parts=self.P, fanouts=fanouts, max_batch=batch,
                                n_streams=streams, n_slots=self.SLOTS, device=device, mode=_abi.MODE_GRAPH,
                                workload=workload, part_mask=(1 << rank) if self.rank_path else 0,
@@ -187,7 +191,9 @@ class Trainer(object):
             # gather of owned input features (row v // P of the owner v % P), int32 indices, float4 row kernel
             _roctx.push("gather")
             rows = deep.in_nodes if self.P == 1 else self.local_row[deep.in_nodes.long()]
-            if self.kind == "gat" and not self.rank_path and self.P == 1 and not splitgnn._NO_LOCAL_FUSE:
+            if self.kind == "gat" and getattr(self, "gat_input", False):
+                x = aggr.FeatureRows(self.feat, rows)       # the deepest layer reads the table through in_nodes
+            elif self.kind == "gat" and not self.rank_path and self.P == 1 and not splitgnn._NO_LOCAL_FUSE:
                 # straight into the row-padded buffer the fused GAT layer multiplies (no second copy of 0.3 GB)
                 x = aggr.padded_rows(rows.numel(), self.feat.shape[1], splitgnn.ROW_PAD, self.dev)
                 aggr.gather_rows(self.feat, rows, out=x.t[:x.n])

@@ -1,0 +1,531 @@
+// gat_input.hip -- the INPUT layer of the multi-head attention model (BASELINE config 5), aggregate-then-project (gfx950).
+//
+// DistGATConv (cslicer/splitgnn.py; the reference's python/layers/dist_gatconv.py is a stub, python/data/bipartite.py:75-80
+// `attention_gather` its only piece) projects every SOURCE row first: z = W x, el = <z, a_l>, er = <z, a_r>, then
+// out[v] = sum_u alpha(u -> v) z[u].  At the deepest layer that is a projection of ~10 source rows per destination
+// (config 5: 0.5 M rows x 100 -> 256, 25.6 GFLOP forward and the same again for the weight gradient) of which nine tenths
+// only exist to be averaged.  Both the logits and the sum are LINEAR in x, so for a layer whose input takes no gradient
+// (the feature table) the same numbers come from the raw rows:
+//     v_l[h] = W_h^T a_l[h]  (H x F, tiny)          el[u, h] = <x[u], v_l[h]>      er[v, h] = <x[v], v_r[h]>
+//     agg[v, h, :] = sum_u alpha_h(u -> v) x[u]     out[v, h, :] = W_h agg[v, h, :] + bias
+// i.e. an attention-weighted sum of RAW feature rows per head (HBM-bound gather, this file), then a block-diagonal
+// projection of the destinations only (H small GEMMs over n_out rows, csl_gemm_f32 batched): 10x fewer flops, no projected
+// source matrix, no gathered input matrix (x is read through the slice's in_nodes), no by-source slice for this layer.
+// Backward: dW_h = g_h^T agg_h and dagg_h = g_h W_h (batched GEMMs), then ONE pass over the edges (k_gatin_bwd) turns dagg
+// into the gradients of v_l and v_r: a source's logit is recomputed per EDGE in the forward (sources of a sampled layer are
+// nearly all distinct), so its gradient needs no per-source accumulation either.
+//
+// Layout: a destination row belongs to 32 lanes (two rows per wave), lane q holds columns 4q..4q+3 of a feature row
+// (F <= 128, F % 4 == 0); the H x (32 / H) dot products of a group of 32 / H edges are reduced across the 32 lanes by a
+// halving exchange (31 shuffles for 32 values) that leaves value i = edge_in_group * H + head in lane i.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "cslicer_aggr.h"
+#include "cslicer_hip.h"
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int RPB = BLK / 32;   // destination rows per block and pass
+constexpr int GATIN_MAX_DEG = 32;
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void fma4(float4& acc, const float s, const float4 v) {
+  acc.x += s * v.x, acc.y += s * v.y, acc.z += s * v.z, acc.w += s * v.w;
+}
+
+// Sum of V values (V = 2^k <= 32) over the 32 lanes of a row group.  While more than one value is left a step halves
+// them: a lane keeps the half its bit selects and receives the partner's share of it.  Returns in lane q the total of
+// value q >> (5 - k).
+template <int V>
+__device__ __forceinline__ float treduce32(float (&v)[V], const int q) {
+  int n = V;
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) {
+    // the selection as bit arithmetic (one v_bfi_b32): written `up ? v[i + hn] : v[i]` the compiler turns it into ONE load
+    // of v[i + (up ? hn : 0)], a per-lane index into a register array, and lowers that to a chain of 31 compares and
+    // selects per value (5,800 of each in a kernel of 350 fmas)
+    const unsigned m = (q & d) ? 0xffffffffu : 0u;
+    if (n > 1) {
+      const int hn = n >> 1;
+#pragma unroll
+      for (int i = 0; i < V / 2; i++) {
+        if (i < hn) {
+          const unsigned lo = __float_as_uint(v[i]), hi = __float_as_uint(v[i + hn]);
+          const float keep = __uint_as_float((hi & m) | (lo & ~m));
+          const float send = __uint_as_float((lo & m) | (hi & ~m));
+          v[i] = keep + __shfl_xor(send, d);
+        }
+      }
+      n = hn;
+    } else {
+      v[0] += __shfl_xor(v[0], d);
+    }
+  }
+  return v[0];
+}
+
+template <int H>
+struct Hlog;
+template <> struct Hlog<1> { static constexpr int k = 0; };
+template <> struct Hlog<2> { static constexpr int k = 1; };
+template <> struct Hlog<4> { static constexpr int k = 2; };
+template <> struct Hlog<8> { static constexpr int k = 3; };
+
+__device__ __forceinline__ float leaky(const float x, const float slope) { return x > 0.f ? x : slope * x; }
+
+// A kernel instance covers rows of at most ME edges (a multiple of the 32 / H edges of a reduction group) and keeps their
+// feature rows in registers between its two passes over the edges: ME = 12 (48 registers) covers config 5's fanout of 10,
+// ME = 32 anything the layer accepts.
+
+// The index chain of a row, ONE hop per level for all its edges: lane q takes edge q (indices, then rowmap), the row ids are
+// handed out with shuffles.  (An edge at a time it was three dependent memory round trips per group of edges and again per
+// group in the second pass: 0.9 ms for the 110 k rows of config 5's deepest layer at two waves per SIMD.)
+struct RowIdx {
+  int e0, deg, sid;
+  int xrow_q;   // lane q: feature row of edge q (of edge 0 for q >= deg)
+  int srow;     // feature row of the destination itself (0 if it has none)
+};
+__device__ __forceinline__ RowIdx load_row_idx(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                               const int* __restrict__ self_ids, const int* __restrict__ rowmap,
+                                               const long long r, const bool rowok, const int q, const int me) {
+  RowIdx ri;
+  ri.e0 = 0, ri.deg = 0, ri.sid = -1;
+  if (rowok) {
+    ri.e0 = indptr[r];
+    ri.deg = indptr[r + 1] - ri.e0;
+    if (ri.deg > me) ri.deg = me;   // (memory safety only: the host side refuses longer rows)
+    ri.sid = self_ids[r];
+  }
+  const int src = indices[q < ri.deg ? ri.e0 + q : (ri.deg > 0 ? ri.e0 : 0)];   // unconditional, always a valid entry
+  ri.srow = ri.sid >= 0 ? (rowmap ? rowmap[ri.sid] : ri.sid) : 0;
+  ri.xrow_q = rowmap ? rowmap[src] : src;
+  return ri;
+}
+
+// forward: agg[r, h, :] = sum_e alpha[e, h] x[src_e];  alpha[e, h] (its sign bit: the logit was <= 0) is kept for the
+// backward.  Rows with more than GATIN_MAX_DEG edges are refused by the host side (the slicer's fanout bounds them).
+template <int H, int ME>
+__global__ __launch_bounds__(BLK) void k_gatin_fwd(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                   const int* __restrict__ self_ids, const int* __restrict__ rowmap,
+                                                   const float* __restrict__ x, long long ldx, int F,
+                                                   const float* __restrict__ vl, const float* __restrict__ vr, float slope,
+                                                   long long n_out, float* __restrict__ agg, float* __restrict__ alpha) {
+  constexpr int EPG = 32 / H;              // edges per reduction group
+  constexpr int NG = ME / EPG;             // groups of a row
+  static_assert(ME % EPG == 0 && ME <= GATIN_MAX_DEG, "whole groups");
+  __shared__ __attribute__((aligned(16))) float s_al[RPB][ME * H];
+  const int q = threadIdx.x & 31, g = threadIdx.x >> 5, half = threadIdx.x & 32;
+  const long long r = (long long)blockIdx.x * RPB + g;
+  const bool rowok = r < n_out;
+  const bool on = 4 * q < F;
+  const int col = on ? 4 * q : 0;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const RowIdx ri = load_row_idx(indptr, indices, self_ids, rowmap, r, rowok, q, ME);
+  const int e0 = ri.e0, deg = ri.deg;
+  const int degmax = max(deg, __shfl_xor(deg, 32));          // wave-uniform
+  // every feature row the first pass needs is requested before any is used
+  float4 xe[ME];
+#pragma unroll
+  for (int j = 0; j < ME; j++) {
+    const long long row = __shfl(ri.xrow_q, half | j);
+    xe[j] = *reinterpret_cast<const float4*>(x + row * ldx + col);
+  }
+  float4 xs = *reinterpret_cast<const float4*>(x + ri.srow * ldx + col);
+  if (!on || ri.sid < 0) xs = zero4;
+#pragma unroll
+  for (int j = 0; j < ME; j++)
+    if (!on || j >= deg) xe[j] = zero4;
+  float4 wl[H];
+  float er_mine;
+  {
+    float pv[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      float4 w = *reinterpret_cast<const float4*>(vr + h * F + col);
+      if (!on) w = zero4;
+      pv[h] = dot4(xs, w);
+      wl[h] = *reinterpret_cast<const float4*>(vl + h * F + col);
+      if (!on) wl[h] = zero4;
+    }
+    const float t = treduce32<H>(pv, q);                     // lane q: head q >> (5 - k)
+    er_mine = __shfl(t, half | ((q & (H - 1)) << (5 - Hlog<H>::k)));  // -> head q % H
+  }
+  float lg[NG];
+  unsigned negbits = 0;
+#pragma unroll
+  for (int c = 0; c < NG; c++) {
+    lg[c] = -1e30f;
+    if (c * EPG < degmax) {                                  // wave-uniform
+      float v[32];
+#pragma unroll
+      for (int j = 0; j < EPG; j++)
+#pragma unroll
+        for (int h = 0; h < H; h++) v[j * H + h] = dot4(xe[c * EPG + j], wl[h]);
+      const float t = treduce32<32>(v, q);                   // lane q: edge q / H of the group, head q % H
+      __builtin_amdgcn_sched_barrier(0);                     // (groups interleaved by the scheduler: 32 more registers each)
+      const float raw = t + er_mine;
+      if (c * EPG + q / H < deg) {
+        lg[c] = leaky(raw, slope);
+        if (!(raw > 0.f)) negbits |= 1u << c;
+      }
+    }
+  }
+  // softmax over the row's edges, per head: lanes q, q ^ H, q ^ 2H, ... hold the same head
+  float m = lg[0];
+#pragma unroll
+  for (int c = 1; c < NG; c++) m = fmaxf(m, lg[c]);
+#pragma unroll
+  for (int d = H; d < 32; d <<= 1) m = fmaxf(m, __shfl_xor(m, d));
+  float p[NG], s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NG; c++) {
+    p[c] = c * EPG + q / H < deg ? __expf(lg[c] - m) : 0.f;
+    s += p[c];
+  }
+#pragma unroll
+  for (int d = H; d < 32; d <<= 1) s += __shfl_xor(s, d);
+  const float inv = s > 0.f ? 1.f / s : 0.f;
+#pragma unroll
+  for (int c = 0; c < NG; c++) {
+    const float a = p[c] * inv;
+    s_al[g][c * 32 + q] = a;
+    if (c * EPG + q / H < deg)
+      alpha[(long long)(e0 + c * EPG) * H + q] = ((negbits >> c) & 1u) ? -a : a;   // 32 consecutive floats per group
+  }
+  __syncthreads();
+  float4 acc[H];
+#pragma unroll
+  for (int h = 0; h < H; h++) acc[h] = zero4;
+#pragma unroll
+  for (int j = 0; j < ME; j++) {
+    if (j < degmax) {                                        // wave-uniform
+      asm volatile("" ::: "memory");   // (all 12 x 8 weights read ahead would cost 96 registers)
+#pragma unroll
+      for (int h = 0; h < H; h++) fma4(acc[h], s_al[g][j * H + h], xe[j]);   // (zero weights and rows for j >= deg)
+    }
+  }
+  if (rowok && on) {
+#pragma unroll
+    for (int h = 0; h < H; h++) *reinterpret_cast<float4*>(agg + (r * H + h) * F + col) = acc[h];
+  }
+}
+
+// backward: from dagg[r, h, :] (row stride ld_r, head stride ld_h) and the kept alpha, the gradients of v_l and v_r as
+// per-block partial sums part_l / part_r [blocks][H * F] (second stage: csl_reduce_multi_f32).
+//   dalpha[e, h] = <dagg[r, h], x[src_e]>      dlogit = alpha (dalpha - sum_e alpha dalpha)      draw = dlogit * leaky'
+//   dv_l[h] += draw[e, h] x[src_e]             dv_r[h] += (sum_e draw[e, h]) x[self(r)]
+template <int H, int ME>
+__global__ __launch_bounds__(BLK) void k_gatin_bwd(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                                   const int* __restrict__ self_ids, const int* __restrict__ rowmap,
+                                                   const float* __restrict__ x, long long ldx, int F,
+                                                   const float* __restrict__ alpha, const float* __restrict__ dagg,
+                                                   long long ld_r, long long ld_h, float slope, long long n_out,
+                                                   long long rows_per_block, float* __restrict__ part_l,
+                                                   float* __restrict__ part_r) {
+  constexpr int EPG = 32 / H;
+  constexpr int NG = ME / EPG;
+  static_assert(ME % EPG == 0 && ME <= GATIN_MAX_DEG, "whole groups");
+  __shared__ __attribute__((aligned(16))) float s_dr[RPB][ME * H];
+  __shared__ __attribute__((aligned(16))) float s_der[RPB][8];
+  __shared__ float4 s_red[RPB][32];
+  __shared__ float4 s_accr[RPB][H][32];   // the v_r side's sums live in LDS: 32 registers less per lane
+  const int q = threadIdx.x & 31, g = threadIdx.x >> 5, half = threadIdx.x & 32;
+  const bool on = 4 * q < F;
+  const int col = on ? 4 * q : 0;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r_end = r0 + rows_per_block < n_out ? r0 + rows_per_block : n_out;
+  float4 accl[H];
+#pragma unroll
+  for (int h = 0; h < H; h++) {
+    accl[h] = zero4;
+    s_accr[g][h][q] = zero4;
+  }
+  // the index chain of the NEXT pass's row is requested while this pass's row is worked on
+  RowIdx nx = load_row_idx(indptr, indices, self_ids, rowmap, r0 + g, r0 + g < r_end, q, ME);
+  for (long long rb = r0; rb < r_end; rb += RPB) {           // block-uniform
+    const long long r = rb + g;
+    const bool rowok = r < r_end;
+    const RowIdx ri = nx;
+    const int e0 = ri.e0, deg = ri.deg;
+    const int degmax = max(deg, __shfl_xor(deg, 32));
+    float4 xe[ME];
+#pragma unroll
+    for (int j = 0; j < ME; j++) {
+      const long long row = __shfl(ri.xrow_q, half | j);
+      xe[j] = *reinterpret_cast<const float4*>(x + row * ldx + col);
+    }
+    float4 xs = *reinterpret_cast<const float4*>(x + ri.srow * ldx + col);
+    const long long rr = rowok ? r : 0;
+    float4 da[H];
+#pragma unroll
+    for (int h = 0; h < H; h++) da[h] = *reinterpret_cast<const float4*>(dagg + rr * ld_r + h * ld_h + col);
+    float av[NG];
+#pragma unroll
+    for (int c = 0; c < NG; c++) {
+      const bool mine = c * EPG + q / H < deg;
+      av[c] = alpha[mine ? (long long)(e0 + c * EPG) * H + q : 0];
+      if (!mine) av[c] = 0.f;
+    }
+    nx = load_row_idx(indptr, indices, self_ids, rowmap, r + RPB, r + RPB < r_end, q, ME);
+    if (!on || ri.sid < 0) xs = zero4;
+#pragma unroll
+    for (int j = 0; j < ME; j++)
+      if (!on || j >= deg) xe[j] = zero4;
+#pragma unroll
+    for (int h = 0; h < H; h++)
+      if (!on || !rowok) da[h] = zero4;
+    float dal[NG];
+    float tsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NG; c++) {
+      dal[c] = 0.f;
+      if (c * EPG < degmax) {                                // wave-uniform
+        float v[32];
+#pragma unroll
+        for (int j = 0; j < EPG; j++)
+#pragma unroll
+          for (int h = 0; h < H; h++) v[j * H + h] = dot4(xe[c * EPG + j], da[h]);
+        dal[c] = treduce32<32>(v, q);
+        __builtin_amdgcn_sched_barrier(0);                   // (groups interleaved by the scheduler: 32 more registers each)
+        tsum += fabsf(av[c]) * dal[c];
+      }
+    }
+#pragma unroll
+    for (int d = H; d < 32; d <<= 1) tsum += __shfl_xor(tsum, d);
+    float der = 0.f;
+#pragma unroll
+    for (int c = 0; c < NG; c++) {
+      // (the sign bit of alpha: the logit was <= 0; -0.0f keeps it for a weight that underflowed)
+      const float dr = fabsf(av[c]) * (dal[c] - tsum) * ((__float_as_uint(av[c]) >> 31) ? slope : 1.f);
+      s_dr[g][c * 32 + q] = dr;
+      der += dr;
+    }
+#pragma unroll
+    for (int d = H; d < 32; d <<= 1) der += __shfl_xor(der, d);
+    if (q < H) s_der[g][q] = der;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ME; j++) {
+      if (j < degmax) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < H; h++) fma4(accl[h], s_dr[g][j * H + h], xe[j]);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      float4 t = s_accr[g][h][q];
+      fma4(t, s_der[g][h], xs);
+      s_accr[g][h][q] = t;
+    }
+    __syncthreads();   // s_dr / s_der are rewritten by the next pass
+  }
+  // the block's sums: over its RPB row groups, head by head
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      s_red[g][q] = side ? s_accr[g][h][q] : accl[h];
+      __syncthreads();
+      if (g == 0) {
+        float4 t = s_red[0][q];
+#pragma unroll
+        for (int k = 1; k < RPB; k++) {
+          const float4 u = s_red[k][q];
+          t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+        }
+        if (on) *reinterpret_cast<float4*>((side ? part_r : part_l) + ((long long)blockIdx.x * H + h) * F + col) = t;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// y[r, c] = act(y[r, c] + bias[c]) in place (ELU with alpha = 1 when elu), C % 4 == 0
+__global__ __launch_bounds__(BLK) void k_bias_elu(float* __restrict__ y, long long ldy, const float* __restrict__ bias,
+                                                  long long n, int C, int elu) {
+  const int qpr = C / 4;
+  const long long i = (long long)blockIdx.x * BLK + threadIdx.x;
+  if (i >= n * qpr) return;
+  const long long r = i / qpr;
+  const int c = (int)(i - r * qpr) * 4;
+  float4 v = *reinterpret_cast<float4*>(y + r * ldy + c);
+  const float4 b = *reinterpret_cast<const float4*>(bias + c);
+  v.x += b.x, v.y += b.y, v.z += b.z, v.w += b.w;
+  if (elu) {
+    v.x = v.x > 0.f ? v.x : expm1f(v.x);
+    v.y = v.y > 0.f ? v.y : expm1f(v.y);
+    v.z = v.z > 0.f ? v.z : expm1f(v.z);
+    v.w = v.w > 0.f ? v.w : expm1f(v.w);
+  }
+  *reinterpret_cast<float4*>(y + r * ldy + c) = v;
+}
+
+// out[r, :] = g[r, :] * act'(y[r, :]) (ELU: y > 0 ? 1 : y + 1) and the per-block column sums of out (the bias gradient);
+// a block takes rows_per_block rows, thread t the float4 column t % (C/4) of every (BLK / (C/4))-th row
+__global__ __launch_bounds__(BLK) void k_elu_bwd_colsum(const float* __restrict__ g, long long ldg,
+                                                        const float* __restrict__ y, long long ldy, long long n, int C,
+                                                        int elu, float* __restrict__ out, long long ldo,
+                                                        float* __restrict__ part, long long rows_per_block) {
+  __shared__ float4 s_p[BLK];
+  const int qpr = C / 4;             // <= 64
+  const int rows_at_once = BLK / qpr;
+  const int cq = threadIdx.x % qpr, rq = threadIdx.x / qpr;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r_end = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rq < rows_at_once) {
+    for (long long r = r0 + rq; r < r_end; r += rows_at_once) {
+      float4 v = *reinterpret_cast<const float4*>(g + r * ldg + 4 * cq);
+      if (elu) {
+        const float4 o = *reinterpret_cast<const float4*>(y + r * ldy + 4 * cq);
+        v.x *= o.x > 0.f ? 1.f : o.x + 1.f;
+        v.y *= o.y > 0.f ? 1.f : o.y + 1.f;
+        v.z *= o.z > 0.f ? 1.f : o.z + 1.f;
+        v.w *= o.w > 0.f ? 1.f : o.w + 1.f;
+      }
+      *reinterpret_cast<float4*>(out + r * ldo + 4 * cq) = v;
+      sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+    }
+  }
+  s_p[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x < qpr) {
+    float4 t = s_p[threadIdx.x];
+    for (int k = 1; k < rows_at_once; k++) {
+      const float4 u = s_p[k * qpr + threadIdx.x];
+      t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+    }
+    *reinterpret_cast<float4*>(part + (long long)blockIdx.x * C + 4 * threadIdx.x) = t;
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+int done() { return hipGetLastError() == hipSuccess ? CSL_OK : CSL_E_HIP; }
+
+long long bwd_rows(long long n) {   // destination rows per workgroup of k_gatin_bwd / k_elu_bwd_colsum: <= ~1024 workgroups
+  long long rpb = (n + 1023) / 1024;
+  rpb = (rpb + RPB - 1) / RPB * RPB;
+  return rpb < RPB ? RPB : rpb;
+}
+
+bool heads_ok(int H) { return H == 1 || H == 2 || H == 4 || H == 8; }
+
+}  // namespace
+
+extern "C" {
+
+int32_t csl_gat_in_max_degree(void) { return GATIN_MAX_DEG; }
+
+int csl_gat_in_fwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
+                       const float* x, int64_t ldx, int32_t F, const float* vl, const float* vr, int32_t H, float slope,
+                       int64_t n_out, int64_t n_edges, int32_t max_deg, float* agg, float* alpha, void* stream) {
+  if (n_out < 0 || n_edges < 0 || max_deg < 0 || max_deg > GATIN_MAX_DEG || !heads_ok(H) || F < 4 || F % 4 != 0 || F > 128 || ldx % 4 != 0 || ldx < F) return CSL_E_INVALID;
+  if (n_out == 0) return CSL_OK;
+  if (!indptr || !self_ids || !x || !vl || !vr || !agg || !aligned16(x) || !aligned16(vl) || !aligned16(vr) || !aligned16(agg))
+    return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_edges == 0) {   // (no index to read: every row is empty)
+    return hipMemsetAsync(agg, 0, sizeof(float) * (size_t)n_out * H * F, st) == hipSuccess ? CSL_OK : CSL_E_HIP;
+  }
+  if (!indices || !alpha) return CSL_E_INVALID;
+  const unsigned blocks = (unsigned)((n_out + RPB - 1) / RPB);
+#define LAUNCH_GIF(HH, MM)                                                                                             \
+  hipLaunchKernelGGL((k_gatin_fwd<HH, MM>), dim3(blocks), dim3(BLK), 0, st, indptr, indices, self_ids, rowmap, x,          \
+                     (long long)ldx, (int)F, vl, vr, slope, (long long)n_out, agg, alpha)
+  switch (H) {
+    case 1: LAUNCH_GIF(1, 32); break;
+    case 2: if (max_deg <= 16) LAUNCH_GIF(2, 16); else LAUNCH_GIF(2, 32); break;
+    case 4: if (max_deg <= 16) LAUNCH_GIF(4, 16); else LAUNCH_GIF(4, 32); break;
+    default: if (max_deg <= 12) LAUNCH_GIF(8, 12); else LAUNCH_GIF(8, 32); break;
+  }
+#undef LAUNCH_GIF
+  return done();
+}
+
+int64_t csl_gat_in_bwd_scratch(int64_t n_out, int32_t H, int32_t F) {
+  if (n_out <= 0) return 0;
+  const long long rpb = bwd_rows(n_out);
+  return 2 * ((n_out + rpb - 1) / rpb) * (long long)H * F;
+}
+
+int csl_gat_in_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
+                       const float* x, int64_t ldx, int32_t F, const float* alpha, const float* dagg, int64_t ld_r,
+                       int64_t ld_h, int32_t H, float slope, int64_t n_out, int64_t n_edges, int32_t max_deg, float* g_vl,
+                       float* g_vr, float* scratch, void* stream) {
+  if (n_out < 0 || n_edges < 0 || max_deg < 0 || max_deg > GATIN_MAX_DEG || !heads_ok(H) || F < 4 || F % 4 != 0 || F > 128 || ldx % 4 != 0 || ldx < F || ld_r % 4 != 0 ||
+      ld_h % 4 != 0)
+    return CSL_E_INVALID;
+  if (!g_vl || !g_vr || !aligned16(g_vl) || !aligned16(g_vr)) return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_out == 0 || n_edges == 0) {   // no edge: no attention, no gradient through the logits
+    if (hipMemsetAsync(g_vl, 0, sizeof(float) * (size_t)H * F, st) != hipSuccess) return CSL_E_HIP;
+    return hipMemsetAsync(g_vr, 0, sizeof(float) * (size_t)H * F, st) == hipSuccess ? CSL_OK : CSL_E_HIP;
+  }
+  if (!indptr || !indices || !self_ids || !x || !alpha || !dagg || !scratch || !aligned16(x) || !aligned16(dagg) ||
+      !aligned16(scratch))
+    return CSL_E_INVALID;
+  const long long rpb = bwd_rows(n_out);
+  const long long blocks = (n_out + rpb - 1) / rpb;
+  float* part_l = scratch;
+  float* part_r = scratch + blocks * H * F;
+#define LAUNCH_GIB(HH, MM)                                                                                             \
+  hipLaunchKernelGGL((k_gatin_bwd<HH, MM>), dim3((unsigned)blocks), dim3(BLK), 0, st, indptr, indices, self_ids, rowmap, x, \
+                     (long long)ldx, (int)F, alpha, dagg, (long long)ld_r, (long long)ld_h, slope, (long long)n_out, rpb, \
+                     part_l, part_r)
+  switch (H) {
+    case 1: LAUNCH_GIB(1, 32); break;
+    case 2: if (max_deg <= 16) LAUNCH_GIB(2, 16); else LAUNCH_GIB(2, 32); break;
+    case 4: if (max_deg <= 16) LAUNCH_GIB(4, 16); else LAUNCH_GIB(4, 32); break;
+    default: if (max_deg <= 12) LAUNCH_GIB(8, 12); else LAUNCH_GIB(8, 32); break;
+  }
+#undef LAUNCH_GIB
+  if (hipGetLastError() != hipSuccess) return CSL_E_HIP;
+  const float* src[2] = {part_l, part_r};
+  const int64_t nblk[2] = {blocks, blocks};
+  const int32_t Hs[2] = {H * F, H * F};
+  float* dst[2] = {g_vl, g_vr};
+  return csl_reduce_multi_f32(2, src, nblk, Hs, dst, stream);
+}
+
+int csl_bias_elu_f32(float* y, int64_t ldy, const float* bias, int64_t n, int32_t C, int32_t elu, void* stream) {
+  if (n < 0 || C < 4 || C % 4 != 0 || ldy < C || ldy % 4 != 0) return CSL_E_INVALID;
+  if (n == 0) return CSL_OK;
+  if (!y || !bias || !aligned16(y) || !aligned16(bias)) return CSL_E_INVALID;
+  const long long total = n * (C / 4);
+  hipLaunchKernelGGL(k_bias_elu, dim3((unsigned)((total + BLK - 1) / BLK)), dim3(BLK), 0, (hipStream_t)stream, y,
+                     (long long)ldy, bias, (long long)n, (int)C, (int)elu);
+  return done();
+}
+
+int64_t csl_elu_bwd_colsum_scratch(int64_t n, int32_t C) {
+  if (n <= 0) return 0;
+  const long long rpb = bwd_rows(n);
+  return ((n + rpb - 1) / rpb) * (long long)C;
+}
+
+int csl_elu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t n, int32_t C, int32_t elu,
+                           float* out, int64_t ldo, float* colsum, float* scratch, void* stream) {
+  if (n < 0 || C < 4 || C % 4 != 0 || C > 256 || ldg < C || ldg % 4 != 0 || ldo < C || ldo % 4 != 0 || !colsum) return CSL_E_INVALID;
+  if (elu && (ldy < C || ldy % 4 != 0)) return CSL_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) return hipMemsetAsync(colsum, 0, sizeof(float) * (size_t)C, st) == hipSuccess ? CSL_OK : CSL_E_HIP;
+  if (!g || !out || !scratch || (elu && !y) || !aligned16(g) || !aligned16(out) || !aligned16(scratch) || (elu && !aligned16(y)))
+    return CSL_E_INVALID;
+  const long long rpb = bwd_rows(n);
+  const long long blocks = (n + rpb - 1) / rpb;
+  hipLaunchKernelGGL(k_elu_bwd_colsum, dim3((unsigned)blocks), dim3(BLK), 0, st, g, (long long)ldg, y, (long long)ldy,
+                     (long long)n, (int)C, (int)elu, out, (long long)ldo, scratch, rpb);
+  if (hipGetLastError() != hipSuccess) return CSL_E_HIP;
+  const float* src[1] = {scratch};
+  const int64_t nblk[1] = {blocks};
+  const int32_t Hs[1] = {C};
+  float* dst[1] = {colsum};
+  return csl_reduce_multi_f32(1, src, nblk, Hs, dst, stream);
+}
+
+}  // extern "C"
