@@ -126,6 +126,22 @@ int csl_gat_in_bwd_f32(const int32_t* indptr, const int32_t* indices, const int3
                        const float* x, int64_t ldx, int32_t F, const float* alpha, const float* dagg, int64_t ld_r,
                        int64_t ld_h, int32_t H, float slope, int64_t n_out, int64_t n_edges, int32_t max_deg, float* g_vl,
                        float* g_vr, float* scratch, void* stream);
+/* The block-diagonal projection of the destinations and its gradients on the fp32 matrix cores (v_mfma_f32_16x16x4_f32; a
+ * wave owns a head, W_h stationary in registers, operands straight from global memory in operand order):
+ *   csl_gat_in_proj_f32:      out[r, h*D + d] = act(sum_f agg[r, h*F + f] W[h*D + d, f] + bias[h*D + d])   (act: ELU if elu)
+ *   csl_gat_in_proj_bwd_f32:  dagg[r, h*FP + f] = sum_d gg[r, h*D + d] W[h*D + d, f]   (FP = csl_gat_in_proj_fpad(F): whole
+ *                             16-column tiles per head, columns >= F zero: pass ld_r = H * FP, ld_h = FP to csl_gat_in_bwd_f32)
+ *                             gW[h*D + d, f] = sum_r gg[r, h*D + d] agg[r, h*F + f]
+ * agg [n, H*F], W [H*D, F] (torch's Linear.weight), gg [n, ldg].  csl_gat_in_proj_ok(H, F, D): H in {1,2,4,8}, F % 4 == 0,
+ * F <= 128, D in {16, 32, 64}; other shapes: the same three products as strided-batched csl_gemm_f32 calls.
+ * scratch: csl_gat_in_proj_bwd_scratch(H, F, D) floats. */
+int32_t csl_gat_in_proj_ok(int32_t H, int32_t F, int32_t D);
+int32_t csl_gat_in_proj_fpad(int32_t F);
+int csl_gat_in_proj_f32(const float* agg, const float* W, const float* bias, int64_t n, int32_t H, int32_t F, int32_t D,
+                        int32_t elu, float* out, int64_t ldo, void* stream);
+int64_t csl_gat_in_proj_bwd_scratch(int32_t H, int32_t F, int32_t D);
+int csl_gat_in_proj_bwd_f32(const float* gg, int64_t ldg, const float* agg, const float* W, int64_t n, int32_t H, int32_t F,
+                            int32_t D, float* dagg, float* gW, float* scratch, void* stream);
 /* y[r, 0:C) = act(y[r, 0:C) + bias) in place for r < n (act = ELU, alpha 1, when elu != 0; C % 4 == 0), and its
  * backward: out[r, :] = g[r, :] * act'(y[r, :]) (from the activation's OUTPUT: y > 0 ? 1 : y + 1), colsum[C] = the
  * column sums of out (the bias gradient; two-stage).  C <= 256; scratch: csl_elu_bwd_colsum_scratch(n, C) floats. */

@@ -26,7 +26,8 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_sage_step_timing_read", "csl_sage_cat_bwd_t_hub_f32", "csl_sage_cat_bwd_t_hub_scratch",
            "csl_gat_bwd_t_fused_f32", "csl_gat_bwd_t_fused_scratch", "csl_sage_rank_g2_f32", "csl_scatter_rows_f32", "csl_spmm_sum_map_f32",
            "csl_gat_in_max_degree", "csl_gat_in_fwd_f32", "csl_gat_in_bwd_scratch", "csl_gat_in_bwd_f32", "csl_bias_elu_f32",
-           "csl_elu_bwd_colsum_scratch", "csl_elu_bwd_colsum_f32"]
+           "csl_elu_bwd_colsum_scratch", "csl_elu_bwd_colsum_f32", "csl_gat_in_proj_ok", "csl_gat_in_proj_fpad",
+           "csl_gat_in_proj_f32", "csl_gat_in_proj_bwd_scratch", "csl_gat_in_proj_bwd_f32"]
 _ready = False
 
 
@@ -105,6 +106,12 @@ def _lib():
         L.csl_elu_bwd_colsum_scratch.argtypes = [i64, i32]
         L.csl_elu_bwd_colsum_scratch.restype = i64
         L.csl_elu_bwd_colsum_f32.argtypes = [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp, vp, vp]
+        L.csl_gat_in_proj_ok.argtypes = [i32, i32, i32]
+        L.csl_gat_in_proj_fpad.argtypes = [i32]
+        L.csl_gat_in_proj_f32.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp]
+        L.csl_gat_in_proj_bwd_scratch.argtypes = [i32, i32, i32]
+        L.csl_gat_in_proj_bwd_scratch.restype = i64
+        L.csl_gat_in_proj_bwd_f32.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp]
         _ready = True
     return L
 
@@ -939,18 +946,22 @@ class GatInputLayer(torch.autograd.Function):
                                   _p(vr), H, slope, n_out, n_edges, max_deg, _p(agg), _p(alpha), _stream()), "csl_gat_in_fwd_f32")
         out = padded_rows(n_out, Cw, row_pad, dev).t if pad_out else torch.empty((n_out, Cw), dtype=torch.float32,
                                                                                   device=dev)
-        if n_out:
-            # out[:, h*D:(h+1)*D] = agg[:, h*F:(h+1)*F] @ W_h^T: the H matrices interleaved in agg / out rows
+        # out[:, h*D:(h+1)*D] = agg[:, h*F:(h+1)*F] @ W_h^T + bias, ELU: the H matrices interleaved in agg / out rows
+        mfma = bool(L.csl_gat_in_proj_ok(H, F, D)) and not os.environ.get("CSLICER_GAT_IN_LIBGEMM")
+        if n_out and mfma:
+            _chk(L.csl_gat_in_proj_f32(_p(agg), _p(weight), _p(b), n_out, H, F, D, 1 if elu else 0, _p(out), Cw, _stream()),
+                 "csl_gat_in_proj_f32")
+        elif n_out:
             _gemm_batched(0, 1, n_out, D, F, agg, H * F, F, weight, F, D * F, out, Cw, D, H)
             _chk(L.csl_bias_elu_f32(_p(out), Cw, _p(b), n_out, Cw, 1 if elu else 0, _stream()), "csl_bias_elu_f32")
         ctx.save_for_backward(table, rows, weight, al, ar, agg, alpha, out, indptr, indices, self_ids_in)
-        ctx.cfg = (n_out, n_edges, max_deg, H, D, F, slope, bool(elu))
+        ctx.cfg = (n_out, n_edges, max_deg, H, D, F, slope, bool(elu), mfma)
         return out
 
     @staticmethod
     def backward(ctx, g):
         table, rows, weight, al, ar, agg, alpha, out, indptr, indices, self_ids_in = ctx.saved_tensors
-        n_out, n_edges, max_deg, H, D, F, slope, elu = ctx.cfg
+        n_out, n_edges, max_deg, H, D, F, slope, elu, mfma = ctx.cfg
         Cw, dev = H * D, table.device
         L = _lib()
         g = _f32(g)
@@ -958,20 +969,25 @@ class GatInputLayer(torch.autograd.Function):
             g = g.contiguous()
         gg = torch.empty((n_out, Cw), dtype=torch.float32, device=dev)
         g_bias = torch.empty((Cw,), dtype=torch.float32, device=dev)
-        buf = torch.empty((max(int(L.csl_elu_bwd_colsum_scratch(n_out, Cw)), int(L.csl_gat_in_bwd_scratch(n_out, H, F)), 4),),
-                          dtype=torch.float32, device=dev)
+        FP = int(L.csl_gat_in_proj_fpad(F)) if mfma else F     # head stride of dagg (whole 16-column tiles on the MFMA path)
+        buf = torch.empty((max(int(L.csl_elu_bwd_colsum_scratch(n_out, Cw)), int(L.csl_gat_in_bwd_scratch(n_out, H, F)),
+                               int(L.csl_gat_in_proj_bwd_scratch(H, F, D)) if mfma else 0, 4),), dtype=torch.float32, device=dev)
         _chk(L.csl_elu_bwd_colsum_f32(_p(g), g.stride(0), _p(out), Cw, n_out, Cw, 1 if elu else 0, _p(gg), Cw, _p(g_bias),
                                       _p(buf), _stream()), "csl_elu_bwd_colsum_f32")
-        gW = torch.zeros((H, D, F), dtype=torch.float32, device=dev) if not n_out else torch.empty(
-            (H, D, F), dtype=torch.float32, device=dev)
-        dagg = torch.empty((n_out, H * F), dtype=torch.float32, device=dev)
+        gW = torch.empty((H, D, F), dtype=torch.float32, device=dev)
+        dagg = torch.empty((n_out, H * FP), dtype=torch.float32, device=dev)
         g_v = torch.empty((2, H, F), dtype=torch.float32, device=dev)
-        if n_out:
-            # dW_h = g_h^T agg_h  [D, F] (the sum runs over the n_out rows);  dagg_h = g_h W_h  [n_out, F]
+        # dW_h = g_h^T agg_h  [D, F] (the sum runs over the n_out rows);  dagg_h = g_h W_h  [n_out, F]
+        if mfma:
+            _chk(L.csl_gat_in_proj_bwd_f32(_p(gg), Cw, _p(agg), _p(weight), n_out, H, F, D, _p(dagg),
+                                           C.c_void_p(gW.data_ptr()), _p(buf), _stream()), "csl_gat_in_proj_bwd_f32")
+        elif n_out:
             _gemm_batched(1, 0, D, F, n_out, gg, Cw, D, agg, H * F, F, gW, F, D * F, H)
             _gemm_batched(0, 0, n_out, F, D, gg, Cw, D, weight, F, D * F, dagg, H * F, F, H)
+        else:
+            gW.zero_()
         _chk(L.csl_gat_in_bwd_f32(_p(indptr), _p(indices), _p(self_ids_in), _p(rows), _p(table), table.stride(0), F, _p(alpha),
-                                  _p(dagg), H * F, F, H, slope, n_out, n_edges, max_deg, C.c_void_p(g_v[0].data_ptr()),
+                                  _p(dagg), H * FP, FP, H, slope, n_out, n_edges, max_deg, C.c_void_p(g_v[0].data_ptr()),
                                   C.c_void_p(g_v[1].data_ptr()), _p(buf), _stream()), "csl_gat_in_bwd_f32")
         # chain rule through v_l[h] = W_h^T a_l[h] (and v_r)
         Wv = weight.view(H, D, F)

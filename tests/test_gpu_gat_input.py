@@ -23,12 +23,20 @@ def _scale(t):
     return max(1e-3, float(t.abs().max()))
 
 
+@pytest.mark.parametrize("libgemm", [False, True])
 @pytest.mark.parametrize("heads,D,F0,fan,B,elu", [(8, 32, 100, 10, 256, True), (4, 12, 20, 7, 64, False),
                                                   (1, 8, 128, 32, 50, True), (2, 16, 4, 3, 300, True),
-                                                  (8, 4, 36, 17, 128, False)])
-def test_input_layer_matches_the_projecting_layer(mods, heads, D, F0, fan, B, elu, monkeypatch):
-    """one layer, same slice, same parameters: output, weight / attention / bias gradients"""
+                                                  (8, 4, 36, 17, 128, False), (4, 64, 128, 12, 100, True),
+                                                  (2, 32, 64, 20, 77, False), (1, 16, 112, 5, 33, True)])
+def test_input_layer_matches_the_projecting_layer(mods, heads, D, F0, fan, B, elu, libgemm, monkeypatch):
+    """one layer, same slice, same parameters: output, weight / attention / bias gradients.  The block-diagonal projection
+    runs on the MFMA kernels where they cover the shape (D in {16, 32, 64}) and as batched library GEMMs otherwise
+    (libgemm: forced)"""
     abi, aggr, sg = mods
+    if libgemm:
+        if not aggr._lib().csl_gat_in_proj_ok(heads, F0, D):
+            pytest.skip("the shape already runs on the library GEMMs")
+        monkeypatch.setenv("CSLICER_GAT_IN_LIBGEMM", "1")
     from cslicer import l0
     torch.manual_seed(heads * 100 + fan)
     n = 5000
