@@ -2459,7 +2459,10 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     }
     {
       Timed t(e, KN_SAMPLE, st);
-      hipLaunchKernelGGL(k_sample, grid_sample, blk, lds_hist, st, a);
+      // CSL_SAMPLE_LDS_PAD=<bytes>: measurement knob (profiles/r3_sample_occupancy): what k_sample costs at the occupancy
+      // an LDS-staged counting sort inside it (k_scatter folded in: 32 KB per workgroup) would leave it
+      static const size_t lds_pad = getenv("CSL_SAMPLE_LDS_PAD") ? (size_t)atol(getenv("CSL_SAMPLE_LDS_PAD")) : 0;
+      hipLaunchKernelGGL(k_sample, grid_sample, blk, lds_hist + lds_pad, st, a);
     }
     if (l == L - 1) {
       // Snapshot of the streams' positions AFTER this round (tightens the host's bounds without a sync).
