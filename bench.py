@@ -662,10 +662,11 @@ def main():
 
     # ---- BASELINE config 5's model on ONE GPU: 3-layer GAT, 8 heads x 32, fanout 10/10/10, batch 1024 (the reference has a
     # stub layer only, python/layers/dist_gatconv.py:3-6 + bipartite.py:75-80: defined GATConv-style here, "parity
-    # unpinned"); the attention aggregation is HBM-bound gather work, the projections are library GEMMs
+    # unpinned"); the attention aggregation is HBM-bound gather work; the deepest layer aggregates the RAW feature rows per
+    # head and projects the destinations only (csrc/gat_input.hip), the other layers' projections are library GEMMs
     def e2e_gat_leg():
         from cslicer.train import Trainer, synthetic_node_data
-        gfan, heads, hid, n_st = (10, 10, 10), 8, 32, 16
+        gfan, heads, hid, n_st = (10, 10, 10), 8, 32, 32
         feats = lambda own: synthetic_node_data(N, args.e2e_feat, args.e2e_classes, seed=0, rows=own)[0]  # noqa: E731
         labels = lambda own: synthetic_node_data(N, 1, args.e2e_classes, seed=0, rows=own)[1]            # noqa: E731
         tr = Trainer(indptr, indices, feats, labels, args.e2e_classes, rank=0, world=1, fanouts=gfan, batch=B, streams=n_st,
@@ -679,8 +680,11 @@ def main():
         tr.run(steps, first_batch=32, then=(after, n_st))   # (slices as many rounds as it trains)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        units = [{k: v / max(tr.steps_done, 1) for k, v in u.items()} for u in tr.units]   # per step; layer 0 = deepest
+        input_layer = "aggregate-then-project (csl_gat_in_*)" if getattr(tr, "gat_input", False) else "project-then-aggregate"
         tr.close()
         return {"iters_per_sec": steps / dt, "ms_per_iter": 1e3 * dt / steps, "steps": steps,
+                "units_per_step": units, "input_layer": input_layer,
                 "config": "3-layer GAT, %d heads x %d, fanout %s, batch %d, 1 part = 1 GPU, features %d, classes %d, fp32, "
                           "Adam; slice+gather+fwd+bwd+step (BASELINE config 5's shape on one GPU)" % (
                               heads, hid, "/".join(map(str, gfan)), B, args.e2e_feat, args.e2e_classes)}

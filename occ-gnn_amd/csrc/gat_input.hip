@@ -108,7 +108,7 @@ __device__ __forceinline__ RowIdx load_row_idx(const int* __restrict__ indptr, c
 // forward: agg[r, h, :] = sum_e alpha[e, h] x[src_e];  alpha[e, h] (its sign bit: the logit was <= 0) is kept for the
 // backward.  Rows with more than GATIN_MAX_DEG edges are refused by the host side (the slicer's fanout bounds them).
 template <int H, int ME>
-__global__ __launch_bounds__(BLK) void k_gatin_fwd(const int* __restrict__ indptr, const int* __restrict__ indices,
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ME <= 16 ? 3 : 1, 8))) void k_gatin_fwd(const int* __restrict__ indptr, const int* __restrict__ indices,
                                                    const int* __restrict__ self_ids, const int* __restrict__ rowmap,
                                                    const float* __restrict__ x, long long ldx, int F,
                                                    const float* __restrict__ vl, const float* __restrict__ vr, float slope,
@@ -118,12 +118,35 @@ __global__ __launch_bounds__(BLK) void k_gatin_fwd(const int* __restrict__ indpt
   static_assert(ME % EPG == 0 && ME <= GATIN_MAX_DEG, "whole groups");
   __shared__ __attribute__((aligned(16))) float s_al[RPB][ME * H];
   const int q = threadIdx.x & 31, g = threadIdx.x >> 5, half = threadIdx.x & 32;
-  const long long r = (long long)blockIdx.x * RPB + g;
-  const bool rowok = r < n_out;
   const bool on = 4 * q < F;
   const int col = on ? 4 * q : 0;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const RowIdx ri = load_row_idx(indptr, indices, self_ids, rowmap, r, rowok, q, ME);
+  const long long stride = (long long)gridDim.x * RPB;
+  // v_r is used once per row: it lives in LDS (kept in registers across the passes it cost 32 of them and a wave per SIMD)
+  __shared__ float4 s_vr[H][32];
+  if (g == 0) {
+#pragma unroll
+    for (int h = 0; h < H; h++) {
+      float4 w = *reinterpret_cast<const float4*>(vr + h * F + col);
+      if (!on) w = zero4;
+      s_vr[h][q] = w;
+    }
+  }
+  float4 wl[H];
+#pragma unroll
+  for (int h = 0; h < H; h++) {
+    wl[h] = *reinterpret_cast<const float4*>(vl + h * F + col);
+    if (!on) wl[h] = zero4;
+  }
+  __syncthreads();
+  // a workgroup walks rows blockIdx.x * RPB + g, + stride, ...: the index chain of the NEXT pass's row (three dependent
+  // round trips) is requested while this pass's row is worked on
+  RowIdx nx = load_row_idx(indptr, indices, self_ids, rowmap, (long long)blockIdx.x * RPB + g,
+                           (long long)blockIdx.x * RPB + g < n_out, q, ME);
+  for (long long rb = (long long)blockIdx.x * RPB; rb < n_out; rb += stride) {   // block-uniform
+  const long long r = rb + g;
+  const bool rowok = r < n_out;
+  const RowIdx ri = nx;
   const int e0 = ri.e0, deg = ri.deg;
   const int degmax = max(deg, __shfl_xor(deg, 32));          // wave-uniform
   // every feature row the first pass needs is requested before any is used
@@ -134,22 +157,16 @@ __global__ __launch_bounds__(BLK) void k_gatin_fwd(const int* __restrict__ indpt
     xe[j] = *reinterpret_cast<const float4*>(x + row * ldx + col);
   }
   float4 xs = *reinterpret_cast<const float4*>(x + ri.srow * ldx + col);
+  nx = load_row_idx(indptr, indices, self_ids, rowmap, r + stride, r + stride < n_out, q, ME);
   if (!on || ri.sid < 0) xs = zero4;
 #pragma unroll
   for (int j = 0; j < ME; j++)
     if (!on || j >= deg) xe[j] = zero4;
-  float4 wl[H];
   float er_mine;
   {
     float pv[H];
 #pragma unroll
-    for (int h = 0; h < H; h++) {
-      float4 w = *reinterpret_cast<const float4*>(vr + h * F + col);
-      if (!on) w = zero4;
-      pv[h] = dot4(xs, w);
-      wl[h] = *reinterpret_cast<const float4*>(vl + h * F + col);
-      if (!on) wl[h] = zero4;
-    }
+    for (int h = 0; h < H; h++) pv[h] = dot4(xs, s_vr[h][q]);
     const float t = treduce32<H>(pv, q);                     // lane q: head q >> (5 - k)
     er_mine = __shfl(t, half | ((q & (H - 1)) << (5 - Hlog<H>::k)));  // -> head q % H
   }
@@ -210,6 +227,8 @@ __global__ __launch_bounds__(BLK) void k_gatin_fwd(const int* __restrict__ indpt
   if (rowok && on) {
 #pragma unroll
     for (int h = 0; h < H; h++) *reinterpret_cast<float4*>(agg + (r * H + h) * F + col) = acc[h];
+  }
+  __syncthreads();   // s_al is rewritten by the next pass
   }
 }
 
@@ -542,59 +561,74 @@ __global__ __launch_bounds__(64 * BD_WAVES) void k_bd_dagg(const float* __restri
 }
 
 // gW partial sums: a wave owns head h and the rows [rg * rows_per, (rg + 1) * rows_per); k = the rows, four per MFMA.
+// The rows of a tile need not be consecutive d, nor its columns consecutive f: M-tile i takes d = NT m + i and column tile
+// (j2, j) takes f = 64 j2 + 4 n + j, so that a lane's operands of ALL tiles are NT consecutive floats of gg and one float4
+// (two for F > 64) of agg: 3 load instructions per four rows instead of 9 four-byte ones.  (A memory instruction costs this
+// chip's L1 ~27 cycles plus ~8 per 64-byte sector it touches, whatever its width -- measured across these kernels; with
+// 256-byte instructions the kernel was bound by that fixed part: 97 us.  Splitting the tiles over more waves to raise the
+// occupancy doubled the instructions and took 214 us; a software pipeline of the loads 120.)
 // part[rg][h][d][f]; second stage: csl_reduce_multi_f32 over the rg.
-template <int KT, int NT>
+template <int FT, int NT>   // FT = ceil(F / 64) float4 loads per row, NT = D / 16
 __global__ __launch_bounds__(64 * BD_WAVES) void k_bd_dw(const float* __restrict__ gg, long long ldg,
                                                         const float* __restrict__ agg, float* __restrict__ part,
                                                         long long n, int H, int F, long long rows_per) {
-  constexpr int D = 16 * NT;
+  constexpr int D = 16 * NT, CT = 4 * FT;
+  typedef float avec __attribute__((ext_vector_type(NT)));
   const int l = threadIdx.x & 63, m = l & 15, kq = l >> 4;
   const long long gw = (long long)blockIdx.x * BD_WAVES + (threadIdx.x >> 6);
   const int h = (int)(gw % H);
   const long long rg = gw / H;
   const long long r_lo = rg * rows_per, r_hi = r_lo + rows_per < n ? r_lo + rows_per : n;
-  f32x4 acc[NT][KT];
+  f32x4 acc[NT][CT];
 #pragma unroll
-  for (int mt = 0; mt < NT; mt++)
+  for (int i = 0; i < NT; i++)
 #pragma unroll
-    for (int t = 0; t < KT; t++) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < CT; t++) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bool col_ok[FT];
+#pragma unroll
+  for (int j2 = 0; j2 < FT; j2++) col_ok[j2] = 64 * j2 + 4 * m < F;
   constexpr int U = 4;   // k-steps (of four rows) whose operands are requested together
   for (long long r0 = r_lo; r0 < r_hi; r0 += 4 * U) {
-    float a[U][NT], b[U][KT];
+    avec a[U];
+    float4 b[U][FT];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const long long r = r0 + 4 * u + kq;
       const bool ok = r < r_hi;
       const long long rr = ok ? r : r_lo;
+      a[u] = *reinterpret_cast<const avec*>(gg + rr * ldg + h * D + NT * m);
+      if (!ok) a[u] = (avec)(0.f);
 #pragma unroll
-      for (int mt = 0; mt < NT; mt++) {
-        a[u][mt] = gg[rr * ldg + h * D + 16 * mt + m];
-        if (!ok) a[u][mt] = 0.f;
-      }
-#pragma unroll
-      for (int t = 0; t < KT; t++) {
-        const int f = 16 * t + m;
-        b[u][t] = agg[(rr * H + h) * F + (f < F ? f : 0)];
-        if (f >= F) b[u][t] = 0.f;
+      for (int j2 = 0; j2 < FT; j2++) {
+        b[u][j2] = *reinterpret_cast<const float4*>(agg + (rr * H + h) * F + (col_ok[j2] ? 64 * j2 + 4 * m : 0));
+        if (!col_ok[j2]) b[u][j2] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
-      for (int mt = 0; mt < NT; mt++)
+      for (int j2 = 0; j2 < FT; j2++) {
+        const float bv[4] = {b[u][j2].x, b[u][j2].y, b[u][j2].z, b[u][j2].w};
 #pragma unroll
-        for (int t = 0; t < KT; t++) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt], b[u][t], acc[mt][t], 0, 0, 0);
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int i = 0; i < NT; i++)
+            acc[i][4 * j2 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], bv[j], acc[i][4 * j2 + j], 0, 0, 0);
+      }
   }
   float* dst = part + (rg * H + h) * (long long)D * F;
 #pragma unroll
-  for (int mt = 0; mt < NT; mt++)
+  for (int i = 0; i < NT; i++)
 #pragma unroll
-    for (int t = 0; t < KT; t++) {
-      const int f = 16 * t + m;
+    for (int j2 = 0; j2 < FT; j2++)
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-        if (f < F) dst[(long long)(16 * mt + 4 * kq + i) * F + f] = acc[mt][t][i];
-    }
+      for (int c = 0; c < 4; c++) {
+        // C row 4 kq + c of M-tile i is d = NT (4 kq + c) + i; the lane's four column tiles are consecutive f
+        const int d = NT * (4 * kq + c) + i;
+        if (col_ok[j2])
+          *reinterpret_cast<float4*>(dst + (long long)d * F + 64 * j2 + 4 * m) =
+              make_float4(acc[i][4 * j2][c], acc[i][4 * j2 + 1][c], acc[i][4 * j2 + 2][c], acc[i][4 * j2 + 3][c]);
+      }
 }
 
 constexpr int BD_BLOCKS = 512;   // 2048 waves: two workgroups per CU, a multiple of every supported head count
@@ -631,7 +665,8 @@ int csl_gat_in_fwd_f32(const int32_t* indptr, const int32_t* indices, const int3
     return hipMemsetAsync(agg, 0, sizeof(float) * (size_t)n_out * H * F, st) == hipSuccess ? CSL_OK : CSL_E_HIP;
   }
   if (!indices || !alpha) return CSL_E_INVALID;
-  const unsigned blocks = (unsigned)((n_out + RPB - 1) / RPB);
+  long long need = (n_out + RPB - 1) / RPB;
+  const unsigned blocks = (unsigned)(need < 768 ? need : 768);   // three workgroups per CU (all resident) walk the rows
 #define LAUNCH_GIF(HH, MM)                                                                                             \
   hipLaunchKernelGGL((k_gatin_fwd<HH, MM>), dim3(blocks), dim3(BLK), 0, st, indptr, indices, self_ids, rowmap, x,          \
                      (long long)ldx, (int)F, vl, vr, slope, (long long)n_out, agg, alpha)
@@ -772,7 +807,15 @@ int csl_gat_in_proj_bwd_f32(const float* gg, int64_t ldg, const float* agg, cons
   const long long ranges = BD_BLOCKS * BD_WAVES / H;
   long long rows_per = (n + ranges - 1) / ranges;
   rows_per = (rows_per + 15) / 16 * 16;
-  BD_DISPATCH(k_bd_dw, gg, (long long)ldg, agg, scratch, (long long)n, (int)H, (int)F, rows_per);
+#define LAUNCH_DW(FF, NN)                                                                                          \
+  hipLaunchKernelGGL((k_bd_dw<FF, NN>), grid, block, 0, st, gg, (long long)ldg, agg, scratch, (long long)n, (int)H, (int)F, \
+                     rows_per)
+  if (F <= 64) {
+    if (D == 16) LAUNCH_DW(1, 1); else if (D == 32) LAUNCH_DW(1, 2); else LAUNCH_DW(1, 4);
+  } else {
+    if (D == 16) LAUNCH_DW(2, 1); else if (D == 32) LAUNCH_DW(2, 2); else LAUNCH_DW(2, 4);
+  }
+#undef LAUNCH_DW
   if (hipGetLastError() != hipSuccess) return CSL_E_HIP;
   const float* src[1] = {scratch};
   const int64_t nblk[1] = {ranges};

@@ -70,7 +70,8 @@ torch.cuda.synchronize()
 _roctx.pop()
 dt = time.perf_counter() - t0
 print(json.dumps({"e2e_only": True, "model": a.model, "steps": a.steps, "ms_per_step": 1e3 * dt / a.steps,
-                  "iters_per_sec": a.steps / dt, "rank_path": a.rank_path, "overlap": a.overlap, "streams": a.streams}))
+                  "iters_per_sec": a.steps / dt, "rank_path": a.rank_path, "overlap": a.overlap, "streams": a.streams,
+                  "units_per_step": [{k: round(v / max(t.steps_done, 1), 1) for k, v in u.items()} for u in t.units]}))
 t.close()
 if dist is not None:
     dist.destroy_process_group()
