@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "cslicer_aggr.h"
 #include "cslicer_hip.h"
@@ -789,8 +790,15 @@ int csl_gat_in_proj_f32(const float* agg, const float* W, const float* bias, int
   return done();
 }
 
+constexpr int BD_DW_BLOCKS_MAX = 1024;
+int bd_dw_blocks() {   // workgroups of k_bd_dw
+  // (profiles/gat_dw_sweep.sh at config 5's shape: 256 / 512 / 768 / 1024 workgroups 142 / 95 / 83 / 101 us: three waves per
+  // SIMD, all resident)
+  static const int v = getenv("CSL_BD_DW_BLOCKS") ? atoi(getenv("CSL_BD_DW_BLOCKS")) : 768;
+  return v < 8 ? 8 : (v > BD_DW_BLOCKS_MAX ? BD_DW_BLOCKS_MAX : v / 8 * 8);
+}
 int64_t csl_gat_in_proj_bwd_scratch(int32_t H, int32_t F, int32_t D) {
-  return (int64_t)(BD_BLOCKS * BD_WAVES / (H > 0 ? H : 1)) * H * D * F;
+  return (int64_t)(BD_DW_BLOCKS_MAX * BD_WAVES / (H > 0 ? H : 1)) * H * D * F;
 }
 
 int csl_gat_in_proj_bwd_f32(const float* gg, int64_t ldg, const float* agg, const float* W, int64_t n, int32_t H, int32_t F,
@@ -804,11 +812,12 @@ int csl_gat_in_proj_bwd_f32(const float* gg, int64_t ldg, const float* agg, cons
     return CSL_E_INVALID;
   const dim3 grid(BD_BLOCKS), block(64 * BD_WAVES);
   BD_DISPATCH(k_bd_dagg, gg, (long long)ldg, W, dagg, (long long)n, (int)H, (int)F);
-  const long long ranges = BD_BLOCKS * BD_WAVES / H;
+  const long long ranges = (long long)bd_dw_blocks() * BD_WAVES / H;
   long long rows_per = (n + ranges - 1) / ranges;
   rows_per = (rows_per + 15) / 16 * 16;
+  const dim3 grid_dw((unsigned)bd_dw_blocks());
 #define LAUNCH_DW(FF, NN)                                                                                          \
-  hipLaunchKernelGGL((k_bd_dw<FF, NN>), grid, block, 0, st, gg, (long long)ldg, agg, scratch, (long long)n, (int)H, (int)F, \
+  hipLaunchKernelGGL((k_bd_dw<FF, NN>), grid_dw, block, 0, st, gg, (long long)ldg, agg, scratch, (long long)n, (int)H, (int)F, \
                      rows_per)
   if (F <= 64) {
     if (D == 16) LAUNCH_DW(1, 1); else if (D == 32) LAUNCH_DW(1, 2); else LAUNCH_DW(1, 4);
