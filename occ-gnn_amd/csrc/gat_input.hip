@@ -633,6 +633,10 @@ __global__ __launch_bounds__(64 * BD_WAVES) void k_bd_dw(const float* __restrict
 }
 
 constexpr int BD_BLOCKS = 512;   // 2048 waves: two workgroups per CU, a multiple of every supported head count
+int bd_blocks() {   // workgroups of k_bd_proj / k_bd_dagg (CSL_BD_BLOCKS: measurement knob, an even number)
+  static const int v = getenv("CSL_BD_BLOCKS") ? atoi(getenv("CSL_BD_BLOCKS")) : BD_BLOCKS;
+  return v < 2 ? 2 : (v > 4096 ? 4096 : v / 2 * 2);
+}
 
 int bd_kt(int F) { return F <= 64 ? 4 : (F <= 112 ? 7 : 8); }
 bool bd_ok(int H, int F, int D) { return (H == 1 || H == 2 || H == 4 || H == 8) && F >= 4 && F % 4 == 0 && F <= 128 && (D == 16 || D == 32 || D == 64); }
@@ -785,7 +789,7 @@ int csl_gat_in_proj_f32(const float* agg, const float* W, const float* bias, int
   if (n == 0) return CSL_OK;
   if (!agg || !W || !bias || !out || !aligned16(agg) || !aligned16(W)) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(BD_BLOCKS), block(64 * BD_WAVES);
+  const dim3 grid(bd_blocks()), block(64 * BD_WAVES);
   BD_DISPATCH(k_bd_proj, agg, W, bias, out, (long long)ldo, (long long)n, (int)H, (int)F, (int)elu);
   return done();
 }
@@ -810,7 +814,7 @@ int csl_gat_in_proj_bwd_f32(const float* gg, int64_t ldg, const float* agg, cons
   if (!gg || !agg || !W || !dagg || !scratch || !aligned16(gg) || !aligned16(agg) || !aligned16(W) || !aligned16(scratch) ||
       !aligned16(gW))
     return CSL_E_INVALID;
-  const dim3 grid(BD_BLOCKS), block(64 * BD_WAVES);
+  const dim3 grid(bd_blocks()), block(64 * BD_WAVES);
   BD_DISPATCH(k_bd_dagg, gg, (long long)ldg, W, dagg, (long long)n, (int)H, (int)F);
   const long long ranges = (long long)bd_dw_blocks() * BD_WAVES / H;
   long long rows_per = (n + ranges - 1) / ranges;
