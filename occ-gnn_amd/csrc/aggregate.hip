@@ -1326,8 +1326,17 @@ int csl_gat_finish_fwd_f32(const float* n_in, const float* s_in, const float* bi
   return done();
 }
 
+// rows per workgroup of k_gat_finish_bwd: a wave walks its rows one after the other (a dependent shuffle chain per row), so a
+// small layer wants MANY small workgroups: with rb_rows' 128 the 8 k-row and 1 k-row layers of config 5's model ran on 64
+// and 8 workgroups, 31-41 us each whatever their size (profiles/r3_gat_in)
+static long long gat_finish_rows(long long n) {
+  long long r = (n + 1023) / 1024;
+  r = (r + 3) / 4 * 4;
+  return r < 4 ? 4 : (r > 128 ? rb_rows(n) : r);
+}
+
 int64_t csl_gat_finish_bwd_scratch(int64_t n, int32_t H, int32_t D) {
-  const long long rpb = rb_rows(n);
+  const long long rpb = gat_finish_rows(n);
   return ((n + rpb - 1) / rpb) * (int64_t)H * D;
 }
 
@@ -1337,7 +1346,7 @@ int csl_gat_finish_bwd_f32(const float* g, int64_t ldg, const float* out, const 
   if (n < 0 || H < 1 || D < 4 || D % 4 != 0 || D > 256 || !g_bias) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int C = H * D;
-  const long long rpb = rb_rows(n);
+  const long long rpb = gat_finish_rows(n);
   const long long blocks = (n + rpb - 1) / rpb;
   if (blocks > 0) {
     if (!g || ldg < C || ldg % 4 != 0 || !n_in || !s_in || !g_n || !g_s || !scratch || (elu && !out) || !aligned16(g) ||
