@@ -142,6 +142,25 @@ int csl_gat_in_proj_f32(const float* agg, const float* W, const float* bias, int
 int64_t csl_gat_in_proj_bwd_scratch(int32_t H, int32_t F, int32_t D);
 int csl_gat_in_proj_bwd_f32(const float* gg, int64_t ldg, const float* agg, const float* W, int64_t n, int32_t H, int32_t F,
                             int32_t D, float* dagg, float* gW, float* scratch, void* stream);
+/* The whole input layer as ONE call per direction (what aggr.GatInputLayer issues where csl_gat_in_proj_ok holds):
+ *   forward : v_l / v_r from W and attn_* (scratch: csl_gat_in_layer_fwd_scratch(H, F) floats), csl_gat_in_fwd_f32,
+ *             csl_gat_in_proj_f32 -> agg [n_out, H*F], alpha [n_edges, H] (both kept for the backward), out [n_out, ldo]
+ *   backward: from g [n_out, ldg] (the gradient of out): ELU' and the bias gradient, dagg / gW (csl_gat_in_proj_bwd_f32), the
+ *             edge pass (csl_gat_in_bwd_f32), ONE second-stage launch for all their sums, then the chain rule through
+ *             v = W_h^T a -> gW [H*D, F] (complete), g_al / g_ar [H, D], g_bias [H*D].  gg [n_out, H*D] and
+ *             dagg [n_out, H * csl_gat_in_proj_fpad(F)] are work buffers; scratch: csl_gat_in_layer_bwd_scratch(...) floats. */
+int64_t csl_gat_in_layer_fwd_scratch(int32_t H, int32_t F);
+int csl_gat_in_layer_fwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
+                             const float* x, int64_t ldx, int32_t F, const float* W, const float* attn_l, const float* attn_r,
+                             const float* bias, int32_t H, int32_t D, float slope, int32_t elu, int64_t n_out, int64_t n_edges,
+                             int32_t max_deg, float* agg, float* alpha, float* out, int64_t ldo, float* scratch, void* stream);
+int64_t csl_gat_in_layer_bwd_scratch(int64_t n_out, int32_t H, int32_t F, int32_t D);
+int csl_gat_in_layer_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
+                             const float* x, int64_t ldx, int32_t F, const float* W, const float* attn_l, const float* attn_r,
+                             int32_t H, int32_t D, float slope, int32_t elu, int64_t n_out, int64_t n_edges, int32_t max_deg,
+                             const float* agg, const float* alpha, const float* out, int64_t ldo, const float* g, int64_t ldg,
+                             float* gg, float* dagg, float* gW, float* g_al, float* g_ar, float* g_bias, float* scratch,
+                             void* stream);
 /* y[r, 0:C) = act(y[r, 0:C) + bias) in place for r < n (act = ELU, alpha 1, when elu != 0; C % 4 == 0), and its
  * backward: out[r, :] = g[r, :] * act'(y[r, :]) (from the activation's OUTPUT: y > 0 ? 1 : y + 1), colsum[C] = the
  * column sums of out (the bias gradient; two-stage).  C <= 256; scratch: csl_elu_bwd_colsum_scratch(n, C) floats. */

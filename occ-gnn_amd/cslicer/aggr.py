@@ -27,7 +27,8 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_gat_bwd_t_fused_f32", "csl_gat_bwd_t_fused_scratch", "csl_sage_rank_g2_f32", "csl_scatter_rows_f32", "csl_spmm_sum_map_f32",
            "csl_gat_in_max_degree", "csl_gat_in_fwd_f32", "csl_gat_in_bwd_scratch", "csl_gat_in_bwd_f32", "csl_bias_elu_f32",
            "csl_elu_bwd_colsum_scratch", "csl_elu_bwd_colsum_f32", "csl_gat_in_proj_ok", "csl_gat_in_proj_fpad",
-           "csl_gat_in_proj_f32", "csl_gat_in_proj_bwd_scratch", "csl_gat_in_proj_bwd_f32"]
+           "csl_gat_in_proj_f32", "csl_gat_in_proj_bwd_scratch", "csl_gat_in_proj_bwd_f32", "csl_gat_in_layer_fwd_scratch",
+           "csl_gat_in_layer_fwd_f32", "csl_gat_in_layer_bwd_scratch", "csl_gat_in_layer_bwd_f32"]
 _ready = False
 
 
@@ -112,6 +113,14 @@ def _lib():
         L.csl_gat_in_proj_bwd_scratch.argtypes = [i32, i32, i32]
         L.csl_gat_in_proj_bwd_scratch.restype = i64
         L.csl_gat_in_proj_bwd_f32.argtypes = [vp, i64, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp]
+        L.csl_gat_in_layer_fwd_scratch.argtypes = [i32, i32]
+        L.csl_gat_in_layer_fwd_scratch.restype = i64
+        L.csl_gat_in_layer_fwd_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, i32, f32, i32, i64, i64, i32,
+                                               vp, vp, vp, i64, vp, vp]
+        L.csl_gat_in_layer_bwd_scratch.argtypes = [i64, i32, i32, i32]
+        L.csl_gat_in_layer_bwd_scratch.restype = i64
+        L.csl_gat_in_layer_bwd_f32.argtypes = [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, i32, i32, f32, i32, i64, i64, i32,
+                                               vp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]
         _ready = True
     return L
 
@@ -937,23 +946,29 @@ class GatInputLayer(torch.autograd.Function):
         rows = _i32(rows) if rows is not None else None
         dev = table.device
         L = _lib()
-        Wv = weight.view(H, D, F)
-        vl = torch.einsum("hdf,hd->hf", Wv, al).contiguous()
-        vr = torch.einsum("hdf,hd->hf", Wv, ar).contiguous()
         agg = torch.empty((n_out, H * F), dtype=torch.float32, device=dev)
         alpha = torch.empty((max(n_edges, 1), H), dtype=torch.float32, device=dev)
-        _chk(L.csl_gat_in_fwd_f32(_p(indptr), _p(indices), _p(self_ids_in), _p(rows), _p(table), table.stride(0), F, _p(vl),
-                                  _p(vr), H, slope, n_out, n_edges, max_deg, _p(agg), _p(alpha), _stream()), "csl_gat_in_fwd_f32")
         out = padded_rows(n_out, Cw, row_pad, dev).t if pad_out else torch.empty((n_out, Cw), dtype=torch.float32,
                                                                                   device=dev)
         # out[:, h*D:(h+1)*D] = agg[:, h*F:(h+1)*F] @ W_h^T + bias, ELU: the H matrices interleaved in agg / out rows
         mfma = bool(L.csl_gat_in_proj_ok(H, F, D)) and not os.environ.get("CSLICER_GAT_IN_LIBGEMM")
-        if n_out and mfma:
-            _chk(L.csl_gat_in_proj_f32(_p(agg), _p(weight), _p(b), n_out, H, F, D, 1 if elu else 0, _p(out), Cw, _stream()),
-                 "csl_gat_in_proj_f32")
-        elif n_out:
-            _gemm_batched(0, 1, n_out, D, F, agg, H * F, F, weight, F, D * F, out, Cw, D, H)
-            _chk(L.csl_bias_elu_f32(_p(out), Cw, _p(b), n_out, Cw, 1 if elu else 0, _stream()), "csl_bias_elu_f32")
+        if mfma:
+            # the whole forward as one native call: v_l / v_r, the edge pass, the projection on the fp32 matrix cores
+            buf = torch.empty((max(int(L.csl_gat_in_layer_fwd_scratch(H, F)), 4),), dtype=torch.float32, device=dev)
+            _chk(L.csl_gat_in_layer_fwd_f32(_p(indptr), _p(indices), _p(self_ids_in), _p(rows), _p(table), table.stride(0), F,
+                                            _p(weight), _p(al), _p(ar), _p(b), H, D, slope, 1 if elu else 0, n_out, n_edges,
+                                            max_deg, _p(agg), _p(alpha), _p(out), Cw, _p(buf), _stream()),
+                 "csl_gat_in_layer_fwd_f32")
+        else:
+            Wv = weight.view(H, D, F)
+            vl = torch.einsum("hdf,hd->hf", Wv, al).contiguous()
+            vr = torch.einsum("hdf,hd->hf", Wv, ar).contiguous()
+            _chk(L.csl_gat_in_fwd_f32(_p(indptr), _p(indices), _p(self_ids_in), _p(rows), _p(table), table.stride(0), F,
+                                      _p(vl), _p(vr), H, slope, n_out, n_edges, max_deg, _p(agg), _p(alpha), _stream()),
+                 "csl_gat_in_fwd_f32")
+            if n_out:
+                _gemm_batched(0, 1, n_out, D, F, agg, H * F, F, weight, F, D * F, out, Cw, D, H)
+                _chk(L.csl_bias_elu_f32(_p(out), Cw, _p(b), n_out, Cw, 1 if elu else 0, _stream()), "csl_bias_elu_f32")
         ctx.save_for_backward(table, rows, weight, al, ar, agg, alpha, out, indptr, indices, self_ids_in)
         ctx.cfg = (n_out, n_edges, max_deg, H, D, F, slope, bool(elu), mfma)
         return out
@@ -970,18 +985,26 @@ class GatInputLayer(torch.autograd.Function):
         gg = torch.empty((n_out, Cw), dtype=torch.float32, device=dev)
         g_bias = torch.empty((Cw,), dtype=torch.float32, device=dev)
         FP = int(L.csl_gat_in_proj_fpad(F)) if mfma else F     # head stride of dagg (whole 16-column tiles on the MFMA path)
-        buf = torch.empty((max(int(L.csl_elu_bwd_colsum_scratch(n_out, Cw)), int(L.csl_gat_in_bwd_scratch(n_out, H, F)),
-                               int(L.csl_gat_in_proj_bwd_scratch(H, F, D)) if mfma else 0, 4),), dtype=torch.float32, device=dev)
-        _chk(L.csl_elu_bwd_colsum_f32(_p(g), g.stride(0), _p(out), Cw, n_out, Cw, 1 if elu else 0, _p(gg), Cw, _p(g_bias),
-                                      _p(buf), _stream()), "csl_elu_bwd_colsum_f32")
         gW = torch.empty((H, D, F), dtype=torch.float32, device=dev)
         dagg = torch.empty((n_out, H * FP), dtype=torch.float32, device=dev)
+        if mfma:
+            # the whole backward as one native call (five kernels, one second-stage launch, the chain rule through v = W^T a)
+            g_a = torch.empty((2, H, D), dtype=torch.float32, device=dev)
+            buf = torch.empty((max(int(L.csl_gat_in_layer_bwd_scratch(n_out, H, F, D)), 4),), dtype=torch.float32, device=dev)
+            _chk(L.csl_gat_in_layer_bwd_f32(_p(indptr), _p(indices), _p(self_ids_in), _p(rows), _p(table), table.stride(0), F,
+                                            _p(weight), _p(al), _p(ar), H, D, slope, 1 if elu else 0, n_out, n_edges, max_deg,
+                                            _p(agg), _p(alpha), _p(out), Cw, _p(g), g.stride(0), _p(gg), _p(dagg),
+                                            C.c_void_p(gW.data_ptr()), C.c_void_p(g_a[0].data_ptr()),
+                                            C.c_void_p(g_a[1].data_ptr()), _p(g_bias), _p(buf), _stream()),
+                 "csl_gat_in_layer_bwd_f32")
+            return (None, None, gW.view(Cw, F), g_a[0], g_a[1], g_bias) + (None,) * 10
+        buf = torch.empty((max(int(L.csl_elu_bwd_colsum_scratch(n_out, Cw)), int(L.csl_gat_in_bwd_scratch(n_out, H, F)), 4),),
+                          dtype=torch.float32, device=dev)
+        _chk(L.csl_elu_bwd_colsum_f32(_p(g), g.stride(0), _p(out), Cw, n_out, Cw, 1 if elu else 0, _p(gg), Cw, _p(g_bias),
+                                      _p(buf), _stream()), "csl_elu_bwd_colsum_f32")
         g_v = torch.empty((2, H, F), dtype=torch.float32, device=dev)
         # dW_h = g_h^T agg_h  [D, F] (the sum runs over the n_out rows);  dagg_h = g_h W_h  [n_out, F]
-        if mfma:
-            _chk(L.csl_gat_in_proj_bwd_f32(_p(gg), Cw, _p(agg), _p(weight), n_out, H, F, D, _p(dagg),
-                                           C.c_void_p(gW.data_ptr()), _p(buf), _stream()), "csl_gat_in_proj_bwd_f32")
-        elif n_out:
+        if n_out:
             _gemm_batched(1, 0, D, F, n_out, gg, Cw, D, agg, H * F, F, gW, F, D * F, H)
             _gemm_batched(0, 0, n_out, F, D, gg, Cw, D, weight, F, D * F, dagg, H * F, F, H)
         else:

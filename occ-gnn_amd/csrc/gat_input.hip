@@ -652,6 +652,70 @@ long long bwd_rows(long long n) {   // destination rows per workgroup of k_gatin
 
 bool heads_ok(int H) { return H == 1 || H == 2 || H == 4 || H == 8; }
 
+// v_l[h, f] = sum_d W[h*D + d, f] attn_l[h, d] (and v_r): the attention vectors pulled back through the projection
+__global__ __launch_bounds__(BLK) void k_gatin_vlr(const float* __restrict__ W, const float* __restrict__ al,
+                                                   const float* __restrict__ ar, int H, int D, int F,
+                                                   float* __restrict__ vlr) {
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= H * F) return;
+  const int h = i / F, f = i - h * F;
+  float sl = 0.f, sr = 0.f;
+  for (int d = 0; d < D; d++) {
+    const float w = W[((long long)h * D + d) * F + f];
+    sl += w * al[h * D + d];
+    sr += w * ar[h * D + d];
+  }
+  vlr[i] = sl;
+  vlr[H * F + i] = sr;
+}
+
+// the chain rule through v = W_h^T a, a wave per row (h, d) of W:
+//   gW[h*D + d, f] += a_l[h, d] g_vl[h, f] + a_r[h, d] g_vr[h, f];   g_al[h, d] = sum_f W[h*D + d, f] g_vl[h, f]  (g_ar likewise)
+__global__ __launch_bounds__(BLK) void k_gatin_chain(const float* __restrict__ W, const float* __restrict__ al,
+                                                     const float* __restrict__ ar, const float* __restrict__ gv, int H, int D,
+                                                     int F, float* __restrict__ gW, float* __restrict__ g_al,
+                                                     float* __restrict__ g_ar) {
+  const int row = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= H * D) return;
+  const int h = row / D;
+  const float a_l = al[row], a_r = ar[row];
+  float sl = 0.f, sr = 0.f;
+  for (int f = lane; f < F; f += 64) {
+    const float w = W[(long long)row * F + f], vl = gv[h * F + f], vr = gv[(H + h) * F + f];
+    gW[(long long)row * F + f] += a_l * vl + a_r * vr;
+    sl += w * vl;
+    sr += w * vr;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sl += __shfl_down(sl, o);
+    sr += __shfl_down(sr, o);
+  }
+  if (lane == 0) {
+    g_al[row] = sl;
+    g_ar[row] = sr;
+  }
+}
+
+// A layer call collects the second stages of its kernels' two-stage sums and runs them as ONE csl_reduce_multi_f32 launch.
+struct DeferredSums {
+  int count;
+  const float* src[8];
+  int64_t nblk[8];
+  int32_t H[8];
+  float* dst[8];
+};
+thread_local DeferredSums* g_defer = nullptr;
+int reduce_or_defer(int count, const float* const* src, const int64_t* nblk, const int32_t* Hs, float* const* dst, void* stream) {
+  if (!g_defer) return csl_reduce_multi_f32(count, src, nblk, Hs, dst, stream);
+  for (int j = 0; j < count; j++) {
+    if (g_defer->count >= 8) return CSL_E_STATE;
+    const int k = g_defer->count++;
+    g_defer->src[k] = src[j], g_defer->nblk[k] = nblk[j], g_defer->H[k] = Hs[j], g_defer->dst[k] = dst[j];
+  }
+  return CSL_OK;
+}
+long long up4(long long v) { return (v + 3) / 4 * 4; }
+
 }  // namespace
 
 extern "C" {
@@ -727,7 +791,7 @@ int csl_gat_in_bwd_f32(const int32_t* indptr, const int32_t* indices, const int3
   const int64_t nblk[2] = {blocks, blocks};
   const int32_t Hs[2] = {H * F, H * F};
   float* dst[2] = {g_vl, g_vr};
-  return csl_reduce_multi_f32(2, src, nblk, Hs, dst, stream);
+  return reduce_or_defer(2, src, nblk, Hs, dst, stream);
 }
 
 int csl_bias_elu_f32(float* y, int64_t ldy, const float* bias, int64_t n, int32_t C, int32_t elu, void* stream) {
@@ -763,7 +827,7 @@ int csl_elu_bwd_colsum_f32(const float* g, int64_t ldg, const float* y, int64_t 
   const int64_t nblk[1] = {blocks};
   const int32_t Hs[1] = {C};
   float* dst[1] = {colsum};
-  return csl_reduce_multi_f32(1, src, nblk, Hs, dst, stream);
+  return reduce_or_defer(1, src, nblk, Hs, dst, stream);
 }
 
 int32_t csl_gat_in_proj_ok(int32_t H, int32_t F, int32_t D) { return bd_ok(H, F, D) ? 1 : 0; }
@@ -834,7 +898,60 @@ int csl_gat_in_proj_bwd_f32(const float* gg, int64_t ldg, const float* agg, cons
   const int64_t nblk[1] = {ranges};
   const int32_t Hs[1] = {H * D * F};
   float* dst[1] = {gW};
-  return csl_reduce_multi_f32(1, src, nblk, Hs, dst, stream);
+  return reduce_or_defer(1, src, nblk, Hs, dst, stream);
+}
+
+/* ---- the whole layer as one call per direction ---- */
+int64_t csl_gat_in_layer_fwd_scratch(int32_t H, int32_t F) { return 2 * (int64_t)H * F; }
+
+int csl_gat_in_layer_fwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
+                             const float* x, int64_t ldx, int32_t F, const float* W, const float* attn_l, const float* attn_r,
+                             const float* bias, int32_t H, int32_t D, float slope, int32_t elu, int64_t n_out, int64_t n_edges,
+                             int32_t max_deg, float* agg, float* alpha, float* out, int64_t ldo, float* scratch, void* stream) {
+  if (!bd_ok(H, F, D) || !W || !attn_l || !attn_r || !scratch || !aligned16(scratch)) return CSL_E_INVALID;
+  hipLaunchKernelGGL(k_gatin_vlr, dim3((unsigned)((H * F + BLK - 1) / BLK)), dim3(BLK), 0, (hipStream_t)stream, W, attn_l, attn_r,
+                     (int)H, (int)D, (int)F, scratch);
+  int rc = csl_gat_in_fwd_f32(indptr, indices, self_ids, rowmap, x, ldx, F, scratch, scratch + (size_t)H * F, H, slope, n_out,
+                              n_edges, max_deg, agg, alpha, stream);
+  if (rc != CSL_OK) return rc;
+  return csl_gat_in_proj_f32(agg, W, bias, n_out, H, F, D, elu, out, ldo, stream);
+}
+
+int64_t csl_gat_in_layer_bwd_scratch(int64_t n_out, int32_t H, int32_t F, int32_t D) {
+  return up4(csl_elu_bwd_colsum_scratch(n_out, H * D)) + up4(csl_gat_in_proj_bwd_scratch(H, F, D)) +
+         up4(csl_gat_in_bwd_scratch(n_out, H, F)) + 2 * (int64_t)H * F;
+}
+
+int csl_gat_in_layer_bwd_f32(const int32_t* indptr, const int32_t* indices, const int32_t* self_ids, const int32_t* rowmap,
+                             const float* x, int64_t ldx, int32_t F, const float* W, const float* attn_l, const float* attn_r,
+                             int32_t H, int32_t D, float slope, int32_t elu, int64_t n_out, int64_t n_edges, int32_t max_deg,
+                             const float* agg, const float* alpha, const float* out, int64_t ldo, const float* g, int64_t ldg,
+                             float* gg, float* dagg, float* gW, float* g_al, float* g_ar, float* g_bias, float* scratch,
+                             void* stream) {
+  if (!bd_ok(H, F, D) || !W || !attn_l || !attn_r || !gW || !g_al || !g_ar || !g_bias || !scratch || !aligned16(scratch) || n_out < 0)
+    return CSL_E_INVALID;
+  const int C = H * D, FP = 16 * bd_kt(F);
+  float* s_elu = scratch;
+  float* s_dw = s_elu + up4(csl_elu_bwd_colsum_scratch(n_out, C));
+  float* s_in = s_dw + up4(csl_gat_in_proj_bwd_scratch(H, F, D));
+  float* g_v = s_in + up4(csl_gat_in_bwd_scratch(n_out, H, F));
+  DeferredSums jobs;
+  jobs.count = 0;
+  g_defer = &jobs;
+  int rc = csl_elu_bwd_colsum_f32(g, ldg, out, ldo, n_out, C, elu, gg, C, g_bias, s_elu, stream);
+  if (rc == CSL_OK) rc = csl_gat_in_proj_bwd_f32(gg, C, agg, W, n_out, H, F, D, dagg, gW, s_dw, stream);
+  if (rc == CSL_OK)
+    rc = csl_gat_in_bwd_f32(indptr, indices, self_ids, rowmap, x, ldx, F, alpha, dagg, (int64_t)H * FP, FP, H, slope, n_out,
+                            n_edges, max_deg, g_v, g_v + (size_t)H * F, s_in, stream);
+  g_defer = nullptr;
+  if (rc != CSL_OK) return rc;
+  if (jobs.count) {
+    rc = csl_reduce_multi_f32(jobs.count, jobs.src, jobs.nblk, jobs.H, jobs.dst, stream);
+    if (rc != CSL_OK) return rc;
+  }
+  hipLaunchKernelGGL(k_gatin_chain, dim3((unsigned)((C + BLK / 64 - 1) / (BLK / 64))), dim3(BLK), 0, (hipStream_t)stream, W, attn_l,
+                     attn_r, g_v, (int)H, (int)D, (int)F, gW, g_al, g_ar);
+  return done();
 }
 
 }  // extern "C"
