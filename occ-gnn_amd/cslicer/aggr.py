@@ -928,11 +928,13 @@ class GatInputLayer(torch.autograd.Function):
     """A DistGATConv layer (+ ELU) of a single part whose input is the FEATURE TABLE (no input gradient), as
     aggregate-then-project (csrc/gat_input.hip): the attention logits and the weighted sum are linear in x, so
         v_l = W_h^T a_l, v_r = W_h^T a_r;  agg[v, h] = sum_u alpha_h(u -> v) x[u]  (csl_gat_in_fwd_f32, raw rows through
-        `rows`);  out[v, h] = W_h agg[v, h] + bias  (H GEMMs over the n_out DESTINATIONS, one batched csl_gemm_f32)
+        `rows`);  out[v, h] = W_h agg[v, h] + bias  (H GEMMs over the n_out DESTINATIONS)
     equals GatLayerLocal on the gathered rows up to fp32 rounding, with a tenth of its flops and without the projected
-    source matrix, the gathered input matrix or the layer's slice by source.  Backward: dW_h = g_h^T agg_h, dagg_h = g_h W_h
-    (batched GEMMs), one pass over the edges for the gradients of v_l / v_r (csl_gat_in_bwd_f32), then the chain rule
-    through v = W^T a."""
+    source matrix, the gathered input matrix or the layer's slice by source.  Backward: dW_h = g_h^T agg_h, dagg_h = g_h W_h,
+    one pass over the edges for the gradients of v_l / v_r (csl_gat_in_bwd_f32), then the chain rule through v = W^T a.
+    Where the fp32-MFMA projection kernels cover the shape (csl_gat_in_proj_ok: D in {16, 32, 64}) each direction is ONE
+    native call (csl_gat_in_layer_fwd_f32 / _bwd_f32); otherwise the products are strided-batched csl_gemm_f32 calls and
+    the small pieces torch ops."""
 
     @staticmethod
     def forward(ctx, table, rows, weight, attn_l, attn_r, bias, indptr, indices, self_ids_in, n_out, n_edges, max_deg, slope,

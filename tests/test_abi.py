@@ -88,3 +88,33 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".c")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt, os.path.join(dp, f)
+
+
+def test_gat_input_layer_host_side_contract():
+    """The attention input layer's pure-host entry points (include/cslicer_aggr.h, csrc/gat_input.hip): which shapes the
+    MFMA projection covers, the padded head stride of dagg, scratch sizes, and argument validation that returns before any
+    HIP call (no GPU here)."""
+    from cslicer import aggr
+    L = aggr._lib()
+    assert L.csl_gat_in_max_degree() == 32
+    assert L.csl_gat_in_proj_ok(8, 100, 32) == 1 and L.csl_gat_in_proj_ok(4, 128, 64) == 1 and L.csl_gat_in_proj_ok(1, 4, 16) == 1
+    assert L.csl_gat_in_proj_ok(3, 100, 32) == 0        # heads: a power of two <= 8
+    assert L.csl_gat_in_proj_ok(8, 100, 12) == 0        # D: whole 16-row tiles
+    assert L.csl_gat_in_proj_ok(8, 132, 32) == 0 and L.csl_gat_in_proj_ok(8, 102, 32) == 0
+    assert [L.csl_gat_in_proj_fpad(f) for f in (4, 64, 68, 100, 112, 116, 128)] == [64, 64, 112, 112, 112, 128, 128]
+    assert L.csl_gat_in_bwd_scratch(0, 8, 100) == 0 and L.csl_gat_in_bwd_scratch(61850, 8, 100) % (2 * 800) == 0
+    assert L.csl_gat_in_layer_fwd_scratch(8, 100) == 1600
+    assert L.csl_gat_in_layer_bwd_scratch(61850, 8, 100, 32) >= (L.csl_elu_bwd_colsum_scratch(61850, 256) +
+                                                                 L.csl_gat_in_proj_bwd_scratch(8, 100, 32) +
+                                                                 L.csl_gat_in_bwd_scratch(61850, 8, 100) + 1600)
+    null, st = C.c_void_p(0), C.c_void_p(0)
+    # H = 3, F % 4 != 0, F > 128, a row longer than the kernels hold: refused, nothing launched
+    assert L.csl_gat_in_fwd_f32(null, null, null, null, null, 100, 100, null, null, 3, 0.2, 10, 10, 10, null, null, st) == -1
+    assert L.csl_gat_in_fwd_f32(null, null, null, null, null, 104, 102, null, null, 8, 0.2, 10, 10, 10, null, null, st) == -1
+    assert L.csl_gat_in_fwd_f32(null, null, null, null, null, 132, 132, null, null, 8, 0.2, 10, 10, 10, null, null, st) == -1
+    assert L.csl_gat_in_fwd_f32(null, null, null, null, null, 100, 100, null, null, 8, 0.2, 10, 10, 33, null, null, st) == -1
+    assert L.csl_gat_in_fwd_f32(null, null, null, null, null, 100, 100, null, null, 8, 0.2, 10, 10, 10, null, null, st) == -1  # null x
+    assert L.csl_gat_in_proj_f32(null, null, null, 10, 8, 100, 12, 1, null, 96, st) == -1
+    assert L.csl_gat_in_layer_fwd_f32(null, null, null, null, null, 100, 100, null, null, null, null, 8, 12, 0.2, 1, 10, 10, 10,
+                                      null, null, null, 96, null, st) == -1
+    assert aggr.gat_input_ok(8, 100, 10) and not aggr.gat_input_ok(8, 100, 33) and not aggr.gat_input_ok(3, 100, 10)
