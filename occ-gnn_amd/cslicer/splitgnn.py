@@ -147,7 +147,11 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
 import os as _os
 _NO_LOCAL_FUSE = bool(_os.environ.get("CSLICER_NO_LOCAL_FUSE"))   # A/B switch for the single-part fused layer
 _NO_GAT_INPUT = bool(_os.environ.get("CSLICER_GAT_NO_INPUT_LAYER"))  # A/B switch: the deepest GAT layer projects its sources
-ROW_PAD = 4096   # GEMM row counts are rounded up to a multiple of this (see DistSageConv.finish)
+# GEMM row counts are rounded up to a multiple of this (see DistSageConv.finish): shapes repeat, weight gradients split into
+# SPLIT_K row slabs.  4096 (rounds 1-2) padded the 6-8 k-row middle layers by a third; the GEMM plans are kept per shape
+# CLASS (long dimension blanked), so a finer quantum costs no tuning: profiles/row_pad_sweep.sh, 4096 / 1024 / 512 / 256:
+# GraphSAGE 2,043 / 2,074 / 2,066 / 2,056, GAT 803 / 847 / 846 / 832 minibatches/s
+ROW_PAD = int(_os.environ.get("CSLICER_ROW_PAD", "1024"))
 SPLIT_K = 32     # the weight-gradient GEMM reduces over the rows in this many independent slabs
 
 
