@@ -30,8 +30,10 @@ def main():
     rows = list(csv.DictReader(open(stats)))
     fetch, write = pmc(os.path.join(src, "fetch")), pmc(os.path.join(src, "write"))
     print("# e2e training step: kernel time and HBM traffic per launch (rocprofv3 PMC)\n")
-    print("Three runs of `profiles/e2e_only.py --steps 128 --streams 64` (products-like graph, 15/10/5, batch 1024, features 100,")
-    print("hidden 256, 47 classes): `--kernel-trace --stats`, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`.  fetched = 2 x FETCH_SIZE")
+    what = sys.argv[2] if len(sys.argv) > 2 else ("`profiles/e2e_only.py --steps 128 --streams 64` (products-like graph, 15/10/5, "
+                                                  "batch 1024, features 100,\nhidden 256, 47 classes)")
+    print("Three runs of %s:" % what)
+    print("`--kernel-trace --stats`, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`.  fetched = 2 x FETCH_SIZE")
     print("(128-byte read requests counted as 64 B on gfx950), written = WRITE_SIZE; GB/s = (fetched + written) / average duration.\n")
     print("| kernel | launches | avg us | share | fetched MiB | written MiB | GB/s |")
     print("|---|---|---|---|---|---|---|")
