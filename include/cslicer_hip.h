@@ -276,6 +276,12 @@ int csl_timing_read(csl_engine* e, double* ms_total /*[CSL_NUM_KERNELS]*/,
                     int64_t* launches /*[CSL_NUM_KERNELS]*/);
 const char* csl_kernel_name(int32_t k);
 
+/* measurement hook (environment CSL_WAVE_DUP_PROBE=1 makes the dedup kernel count): out3 = { queue entries seen, entries
+ * that are not the first of their node id among the 64 entries a wave holds in one register row, ... among all the entries
+ * a wave holds of a bucket } since the library was loaded -- what a wave-level (ballot / swizzle) dedup in front of the LDS
+ * table could remove (north_star; profiles/r3_wave_dup/).  Synchronises the device. */
+int csl_debug_wave_duplicates(uint64_t* out3);
+
 /* device mt19937 stream self-test hook: copies words [pos, pos+n) to dst */
 int csl_rng_peek(csl_engine* e, uint64_t pos, uint32_t* dst, int64_t n);
 

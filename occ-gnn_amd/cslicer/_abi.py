@@ -37,6 +37,7 @@ SYMBOLS = [
     "csl_submit_round", "csl_submit_seeds", "csl_sync", "csl_get_meta", "csl_copy_list",
     "csl_list_device_ptr", "csl_frontier_device_ptr", "csl_copy_frontier", "csl_hip_stream",
     "csl_timing_enable", "csl_timing_read", "csl_kernel_name", "csl_rng_peek", "csl_device_bytes",
+    "csl_debug_wave_duplicates",
     "csl_fetch_sample", "csl_fetch_sample32", "csl_totals", "csl_arena_info", "csl_copy_candidates",
 ]
 

@@ -941,7 +941,12 @@ constexpr int BPB = CSL_BPB;  // buckets a block resolves one after the other; t
 // because a load that MAY be pending in a register makes the compiler wait for the whole memory counter --
 // i.e. for the acknowledgement of every earlier scattered flag store -- before each next store: that wait,
 // not LDS or the stores themselves, was most of this kernel's time (8 us per bucket).
-template <bool HAS_WL>
+// CSL_WAVE_DUP_PROBE=1 (measurement only, csl_debug_wave_duplicates): how many queue entries a WAVE-level dedup in front of
+// the LDS table could remove -- entries whose id another lane of the same wave already holds -- [0] entries seen, [1] not the
+// first of their id among the 64 entries of one register row, [2] among all RC x 64 entries a wave holds of a bucket
+__device__ unsigned long long g_wave_dup[3];
+
+template <bool HAS_WL, bool PROBE = false>
 __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
   uint32_t bx, s;
   if (!xcd_block(a, bx, s)) return;
@@ -1026,6 +1031,32 @@ __global__ __launch_bounds__(BT) void k_bucket(LArgs a) {
     if (b >= nbk) break;  // block-uniform
     const uint2* q = qs + q0;
     const uint32_t cnt = q1 - q0;
+    if (PROBE) {
+      unsigned n_e = 0, n_row = 0, n_all = 0;
+      const uint32_t lane = lane_id();
+#pragma unroll
+      for (int r = 0; r < RC; r++) {
+        bool later_row = false, later_all = false;
+        for (uint32_t sl = 0; sl < 64; sl++) {
+#pragma unroll
+          for (int r2 = 0; r2 < RC; r2++) {
+            const uint32_t other = __shfl(e[r2].x, sl);
+            if (other == e[r].x && (r2 < r || (r2 == r && sl < lane))) {
+              later_all = true;
+              if (r2 == r) later_row = true;
+            }
+          }
+        }
+        if (e[r].x != UNSET) {
+          n_e++;
+          n_row += later_row;
+          n_all += later_all;
+        }
+      }
+      atomicAdd(&g_wave_dup[0], (unsigned long long)n_e);
+      atomicAdd(&g_wave_dup[1], (unsigned long long)n_row);
+      atomicAdd(&g_wave_dup[2], (unsigned long long)n_all);
+    }
     // The next bucket's first entries are requested before this one is resolved.  The loads are issued
     // UNCONDITIONALLY (idle lanes and the last bucket re-read element 0): a load inside a branch would make
     // the compiler wait for the whole memory counter at the next use of any loaded register, prefetch included.
@@ -2486,7 +2517,9 @@ int run_round(csl_engine* e, const long long* nodes_dev, int32_t n_batches, int3
     }
     {
       Timed t(e, KN_BUCKET, st);
-      if (a.wl) hipLaunchKernelGGL(k_bucket<true>, grid_bucket, dim3(BT), 0, st, a);
+      static const bool probe = getenv("CSL_WAVE_DUP_PROBE") != nullptr;
+      if (probe) hipLaunchKernelGGL((k_bucket<false, true>), grid_bucket, dim3(BT), 0, st, a);   // (v % P owners only)
+      else if (a.wl) hipLaunchKernelGGL(k_bucket<true>, grid_bucket, dim3(BT), 0, st, a);
       else hipLaunchKernelGGL(k_bucket<false>, grid_bucket, dim3(BT), 0, st, a);
     }
     {
@@ -2544,6 +2577,15 @@ extern "C" {
 const char* csl_last_error(void) { return g_err; }
 int csl_abi_version(void) { return CSL_ABI_VERSION; }
 const char* csl_kernel_name(int32_t k) { return (k >= 0 && k < CSL_NUM_KERNELS) ? kKernelNames[k] : ""; }
+
+int csl_debug_wave_duplicates(uint64_t* out3) {
+  if (!out3) return CSL_E_INVALID;
+  unsigned long long v[3];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(v, HIP_SYMBOL(g_wave_dup), sizeof(v)) != hipSuccess)
+    return CSL_E_HIP;
+  for (int i = 0; i < 3; i++) out3[i] = v[i];
+  return CSL_OK;
+}
 
 void csl_destroy(csl_engine* e) {
   if (!e) return;
