@@ -498,7 +498,8 @@ class DistGATConv(nn.Module):
             xin = x[g]
             if isinstance(xin, aggr.FeatureRows):
                 # the deepest layer on the resident feature table: aggregate the raw rows, project the destinations
-                if not _NO_GAT_INPUT and aggr.gat_input_ok(self.H, xin.table.shape[1], sl[g].fanout):
+                if (not _NO_GAT_INPUT and not xin.table.requires_grad      # (the layer returns no input gradient)
+                        and aggr.gat_input_ok(self.H, xin.table.shape[1], sl[g].fanout)):
                     out = aggr.GatInputLayer.apply(xin.table, xin.rows, self.fc.weight, self.attn_l, self.attn_r, self.bias,
                                                    sl[g].indptr, sl[g].indices, sl[g].self_ids_in, sl[g].n_out,
                                                    sl[g].n_edges, sl[g].fanout, self.slope, bool(elu), ROW_PAD, bool(pad_out))
