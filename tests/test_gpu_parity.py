@@ -540,3 +540,40 @@ def test_baseline_config3_papers_like_full_size(abi, orc):
     assert e.device_bytes() < 12 * (1 << 30)
     e.close()
     print("papers-like: N=%d E=%d generated in %.0f s" % (n, indices.shape[0], t_gen))
+
+
+def test_wave_duplicate_probe_counts_and_leaves_the_samples_alone():
+    """CSL_WAVE_DUP_PROBE=1 swaps the dedup kernel for its counting instance (csl_debug_wave_duplicates, the measurement
+    behind DESIGN section 3's wave-level-dedup number): in a child process (the switch is read once per process) every
+    golden case must still come out bit-exact, and the counters must say something plausible."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(os.path.dirname(sys.path[0]), "occ-gnn_amd"))
+sys.path.insert(0, os.path.dirname(sys.path[1]))
+from golden_util import CASES, assert_same_sample, load_case
+from cslicer import _abi
+L = _abi.load()
+for case in CASES:
+    indptr, indices, batches = load_case(case)
+    mb = max(len(b["seeds"]) for b in batches)
+    e = _abi.Engine(indptr, indices, n_parts=4, fanouts=(10, 10, 10), max_batch=mb, n_streams=1)
+    for b, want in enumerate(batches):
+        e.submit_seeds([want["seeds"]])
+        assert_same_sample(e.sample_dict(0), want, what="%%s batch %%d (probe build)" %% (case, b), edge_stream=False)
+    e.close()
+out = (C.c_uint64 * 3)()
+L.csl_debug_wave_duplicates.argtypes = [C.POINTER(C.c_uint64)]
+assert L.csl_debug_wave_duplicates(out) == 0
+print("WAVEDUP", int(out[0]), int(out[1]), int(out[2]))
+''' % here
+    env = dict(os.environ, CSL_WAVE_DUP_PROBE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("WAVEDUP")][-1].split()
+    seen, in_row, in_wave = int(line[1]), int(line[2]), int(line[3])
+    assert seen > 0 and 0 <= in_row <= in_wave < seen
