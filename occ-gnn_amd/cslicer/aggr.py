@@ -1021,6 +1021,136 @@ class GatInputLayer(torch.autograd.Function):
         return (None, None, gW.view(Cw, F), g_a[0], g_a[1], g_bias) + (None,) * 10
 
 
+class GatLayerRank(torch.autograd.Function):
+    """A whole DistGATConv layer of ONE part = one process (DistGATConv.forward_rank) as one autograd node: projection
+    (csl_gemm_f32), logits (csl_gat_logits_fwd_f32), the partial edge-softmax state of the local edges (csl_gat_fwd_f32), the
+    two boundary exchanges and the merge at the owners, the epilogue (csl_gat_finish_fwd_f32); the backward by hand with
+    the same kernels' backward halves and the three reverse exchanges.  The exchanges are `comm._exchange` calls over the
+    slice's back-to-back per-peer lists (to_all / from_all): nothing loops over the peers.  As separate autograd nodes
+    (DistGATConv._forward_rank_autograd) the layer was ~150 small launches forward + backward and a rank's share of an
+    8-GPU minibatch a 3.7 ms step whatever its size (profiles/r3_rank/gat_world_of_one.md).
+
+    Merge at the owner of a row, over its own partial state and the peers' (m_p, s_p, n_p):
+        M = max_p m_p;  c_p = exp(m_p - M);  S = sum_p c_p s_p;  N = sum_p c_p n_p;  out = N / S + bias.
+    M and the m_p are stabilisers (the result does not depend on them): no gradient flows through them, so
+        g_N = g_out / S,  g_S = -<g_out, N> / S^2  (csl_gat_finish_bwd_f32),  g_n_p = c_p g_N,  g_s_p = c_p g_S,
+    which travel back to the holders of the edges, whose local backward (csl_gat_bwd_f32) needs only its own m_p."""
+
+    @staticmethod
+    def forward(ctx, x, weight, attn_l, attn_r, bias, sl, comm, slope, elu):
+        H, D = attn_l.shape
+        Cw = H * D
+        x = _f32(x).contiguous()
+        weight = _f32(weight).contiguous()
+        al, ar, b = _f32(attn_l).contiguous(), _f32(attn_r).contiguous(), _f32(bias).contiguous()
+        n_in, n_out, dev = x.shape[0], sl.n_out, x.device
+        L = _lib()
+        indptr, indices = _i32(sl.indptr), _i32(sl.indices)
+        owned, self_in = sl.owned_out_nodes.long(), sl.self_ids_in.long()
+        to_all, from_all = _i32(sl.to_all), _i32(sl.from_all)
+        tl, fl = to_all.long(), from_all.long()
+        to_counts, from_counts = list(sl.to_counts), list(sl.from_counts)
+        multi = comm is not None and comm.world > 1
+        z = gemm(x, weight, transb=True) if n_in else torch.zeros((0, Cw), dtype=torch.float32, device=dev)
+        el = torch.empty((n_in, H), dtype=torch.float32, device=dev)
+        er = torch.empty((n_in, H), dtype=torch.float32, device=dev)
+        _chk(L.csl_gat_logits_fwd_f32(_p(z), _p(al), _p(ar), n_in, H, D, _p(el), _p(er), _stream()), "csl_gat_logits_fwd_f32")
+        # logits of the destinations: own rows from the own projection, the others from their owners
+        er_out = torch.zeros((n_out, H), dtype=torch.float32, device=dev)
+        er_out.index_copy_(0, owned, er.index_select(0, self_in))
+        if multi:
+            recv = comm._exchange(er_out.index_select(0, tl), to_counts, from_counts)
+            er_out.index_copy_(0, fl, recv)
+        m = torch.empty((n_out, H), dtype=torch.float32, device=dev)
+        s_ = torch.empty((n_out, H), dtype=torch.float32, device=dev)
+        n_ = torch.empty((n_out, Cw), dtype=torch.float32, device=dev)
+        _chk(L.csl_gat_fwd_f32(_p(indptr), _p(indices), n_out, _p(el), _p(er_out), _p(z), H, D, slope, _p(m), _p(s_), _p(n_),
+                               _stream()), "csl_gat_fwd_f32")
+        # partial states of the boundary rows to their owners, merged there
+        c_own, c_recv = None, None
+        S, N = s_, n_
+        if multi:
+            pack = torch.cat([m, s_, n_], dim=1)
+            recv = comm._exchange(pack.index_select(0, fl), from_counts, to_counts)          # [len(to_all), 2H + Cw]
+            M = m.clone()
+            if tl.numel():
+                M.scatter_reduce_(0, tl.unsqueeze(1).expand(-1, H), recv[:, :H], "amax", include_self=True)
+            c_own = torch.exp(m - M)
+            S = s_ * c_own
+            N = (n_.view(n_out, H, D) * c_own.unsqueeze(2)).view(n_out, Cw)
+            if tl.numel():
+                c_recv = torch.exp(recv[:, :H] - M.index_select(0, tl))
+                S.index_add_(0, tl, recv[:, H:2 * H] * c_recv)
+                N.view(n_out, H, D).index_add_(0, tl, recv[:, 2 * H:2 * H + Cw].reshape(-1, H, D) * c_recv.unsqueeze(2))
+        S_o = S.index_select(0, owned).contiguous()
+        N_o = N.index_select(0, owned).contiguous()
+        n_owned = owned.numel()
+        out = torch.empty((n_owned, Cw), dtype=torch.float32, device=dev)
+        _chk(L.csl_gat_finish_fwd_f32(_p(N_o), _p(S_o), _p(b), n_owned, H, D, 1 if elu else 0, _p(out), _stream()),
+             "csl_gat_finish_fwd_f32")
+        ctx.save_for_backward(x, weight, al, ar, z, el, er_out, m, S_o, N_o, out, indptr, indices, owned, self_in, tl, fl,
+                              c_own if c_own is not None else torch.empty(0, device=dev),
+                              c_recv if c_recv is not None else torch.empty(0, device=dev))
+        ctx.cfg = (n_in, n_out, H, D, slope, bool(elu), comm if multi else None, to_counts, from_counts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x, weight, al, ar, z, el, er_out, m, S_o, N_o, out, indptr, indices, owned, self_in, tl, fl, c_own,
+         c_recv) = ctx.saved_tensors
+        n_in, n_out, H, D, slope, elu, comm, to_counts, from_counts = ctx.cfg
+        Cw, dev = H * D, x.device
+        L = _lib()
+        g = _f32(g)
+        if g.stride(-1) != 1 or g.stride(0) % 4:
+            g = g.contiguous()
+        n_owned = owned.numel()
+        g_n_o = torch.empty((n_owned, Cw), dtype=torch.float32, device=dev)
+        g_s_o = torch.empty((n_owned, H), dtype=torch.float32, device=dev)
+        buf = torch.empty((3 * Cw + max(int(L.csl_gat_finish_bwd_scratch(n_owned, H, D)),
+                                        2 * int(L.csl_gat_logits_bwd_scratch(n_in, H, D)), 4),), dtype=torch.float32,
+                          device=dev)
+        g_bias, g_al, g_ar = buf[:Cw], buf[Cw:2 * Cw].view(H, D), buf[2 * Cw:3 * Cw].view(H, D)
+        scratch = C.c_void_p(buf.data_ptr() + 12 * Cw)
+        _chk(L.csl_gat_finish_bwd_f32(_p(g), g.stride(0), _p(out), _p(N_o), _p(S_o), n_owned, H, D, 1 if elu else 0, _p(g_n_o),
+                                      _p(g_s_o), _p(g_bias), scratch, _stream()), "csl_gat_finish_bwd_f32")
+        # gradients of the merged state in out-row order, then of every contribution: c_p times them
+        g_s = torch.zeros((n_out, H), dtype=torch.float32, device=dev)
+        g_n = torch.zeros((n_out, Cw), dtype=torch.float32, device=dev)
+        g_s.index_copy_(0, owned, g_s_o)
+        g_n.index_copy_(0, owned, g_n_o)
+        if comm is not None:
+            send = torch.cat([g_s.index_select(0, tl) * c_recv,
+                              (g_n.index_select(0, tl).view(-1, H, D) * c_recv.unsqueeze(2)).view(-1, Cw)], dim=1) \
+                if tl.numel() else torch.zeros((0, H + Cw), dtype=torch.float32, device=dev)
+            recv = comm._exchange(send, to_counts, from_counts)                                # [len(from_all), H + Cw]
+            g_s.mul_(c_own)
+            g_n.view(n_out, H, D).mul_(c_own.unsqueeze(2))
+            if fl.numel():
+                g_s.index_copy_(0, fl, recv[:, :H])
+                g_n.index_copy_(0, fl, recv[:, H:])
+        # the local edges
+        g_el = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
+        g_er_out = torch.empty((n_out, H), dtype=torch.float32, device=dev)
+        g_z = torch.zeros((n_in, Cw), dtype=torch.float32, device=dev)
+        _chk(L.csl_gat_bwd_f32(_p(indptr), _p(indices), n_out, _p(el), _p(er_out), _p(z), H, D, slope, _p(m), _p(g_s), _p(g_n),
+                               _p(g_el), _p(g_er_out), _p(g_z), _stream()), "csl_gat_bwd_f32")
+        # the destinations' logits: boundary rows back to their owners (a row may come back from several peers)
+        if comm is not None:
+            recv = comm._exchange(g_er_out.index_select(0, fl), from_counts, to_counts)
+            if tl.numel():
+                g_er_out.index_add_(0, tl, recv)
+        g_er = torch.zeros((n_in, H), dtype=torch.float32, device=dev)
+        g_er.index_copy_(0, self_in, g_er_out.index_select(0, owned))
+        _chk(L.csl_gat_logits_bwd_acc_f32(_p(z), _p(al), _p(ar), _p(g_el), _p(g_er), n_in, H, D, _p(g_z), 1,
+                                          C.c_void_p(g_al.data_ptr()), C.c_void_p(g_ar.data_ptr()), scratch, _stream()),
+             "csl_gat_logits_bwd_acc_f32")
+        gw = gemm(g_z, x, transa=True) if n_in else torch.zeros_like(weight)
+        gx = gemm(g_z, weight) if ctx.needs_input_grad[0] and n_in else (
+            torch.zeros_like(x) if ctx.needs_input_grad[0] else None)
+        return gx, gw, g_al, g_ar, g_bias, None, None, None, None
+
+
 def attention_gather(indptr, indices, u_in, v_in, n_rows):
     """BipartiteGraph.attention_gather (python/data/bipartite.py:75-80): out[v] = sum over in-edges
     (u, v) of u_in[u] * v_in[v] (DGL u_mul_v + sum).  v_in[v] does not depend on u, so this is the

@@ -146,6 +146,7 @@ def slices_of(eng, stream=0, slot=0, parts=None, device=None, meta=None):
 
 import os as _os
 _NO_LOCAL_FUSE = bool(_os.environ.get("CSLICER_NO_LOCAL_FUSE"))   # A/B switch for the single-part fused layer
+_GAT_RANK_AUTOGRAD = bool(_os.environ.get("CSLICER_GAT_RANK_AUTOGRAD"))   # A/B switch: a rank's GAT layer as separate autograd nodes
 _NO_GAT_INPUT = bool(_os.environ.get("CSLICER_GAT_NO_INPUT_LAYER"))  # A/B switch: the deepest GAT layer projects its sources
 # GEMM row counts are rounded up to a multiple of this (see DistSageConv.finish): shapes repeat, weight gradients split into
 # SPLIT_K row slabs.  4096 (rounds 1-2) padded the 6-8 k-row middle layers by a third; the GEMM plans are kept per shape
@@ -562,7 +563,11 @@ class DistGATConv(nn.Module):
 
 
     def _forward_rank(self, sl, x, comm):
-        """One part per process (DistGATConv.forward_rank): two boundary exchanges per layer."""
+        """One part per process (DistGATConv.forward_rank): two boundary exchanges per layer.  On the GPU the layer is one
+        autograd node (aggr.GatLayerRank: fused kernels, exchanges over the back-to-back per-peer lists);
+        CSLICER_GAT_RANK_AUTOGRAD=1: the node-by-node form below (A/B switch, and what the CPU / gloo tests run)."""
+        if x.is_cuda and not _GAT_RANK_AUTOGRAD:
+            return aggr.GatLayerRank.apply(x, self.fc.weight, self.attn_l, self.attn_r, self.bias, sl, comm, self.slope, False)
         g, P, H, D = sl.part, sl.n_parts, self.H, self.D
         z, el, er = self.project(x)
         er_out = torch.zeros((sl.n_out, H), dtype=torch.float32, device=x.device)

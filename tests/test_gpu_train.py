@@ -184,7 +184,8 @@ def _rank_body(rank, world, q, overlap, kind, dist, table=False):
     t = Trainer(indptr, indices, load(feats) if table else feats, load(labels) if table else labels, 5, rank=rank,
                 world=world, fanouts=(10, 5), batch=128, streams=2, hidden=16, lr=1e-2, dist=dist, overlap=overlap,
                 model=kind, heads=2, workload=wl, feat_dim=feats.shape[1])
-    # GraphSAGE: one native call per step, the exchanges as callbacks (on the side stream with overlap); GAT: autograd
+    # GraphSAGE: one native call per step, the exchanges as callbacks (on the side stream with overlap); GAT: one fused
+    # autograd node per layer (aggr.GatLayerRank)
     assert (t.native_rank is not None) == (kind == "sage")
     if table:
         assert len(asked) == 2 and all(bool((wl[o] == rank).all()) and len(o) == int((wl == rank).sum()) for o in asked)
@@ -253,9 +254,21 @@ def test_two_ranks_match_single_process_two_parts(overlap, kind, table, world):
             ref_losses.append(float(loss))
     w_ref = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()]).numpy()
     eng.close()
+    # GraphSAGE: the ranks run the same kernels in the same order as the single-process reference.  GAT: a rank's layer is
+    # one fused autograd node (aggr.GatLayerRank: csl_gemm_f32 with a timed algorithm choice, other summation orders than
+    # the node-by-node reference), its gradients agree with the node-by-node form to 1e-4 of the largest entry
+    # (test_fused_gat_rank_layer_matches_its_autograd_form) -- and Adam at lr 1e-2 turns noise-level gradient entries into
+    # lr-sized steps, so the trajectories agree to 1e-3, not 1e-5
     for rank, losses, w in res:
-        np.testing.assert_allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(w, w_ref, rtol=1e-4, atol=1e-5)
+        if kind == "gat":
+            np.testing.assert_allclose(losses, ref_losses, rtol=1e-3, atol=1e-6)
+            # (an entry whose gradient is rounding noise -- padded class columns, a nearly empty rank's share -- may have
+            # walked up to 4 lr the other way: a few per cent of the entries)
+            off = np.abs(w - w_ref) > 1e-4 + 1e-3 * np.abs(w_ref)
+            assert off.mean() < 0.1 and np.abs(w - w_ref).max() <= 4 * 1e-2 + 1e-6, (int(off.sum()), off.size)
+        else:
+            np.testing.assert_allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(w, w_ref, rtol=1e-4, atol=1e-5)
 
 
 def test_batch_slice_script_prints_exp5_keys(capsys):
@@ -369,3 +382,72 @@ def test_rccl_calls_on_one_gpu(kind):
     tol = 1e-3 if kind == "gat" else 1e-5
     np.testing.assert_allclose(ranked, plain, rtol=tol, atol=1e-6)
     np.testing.assert_allclose(overlapped, plain, rtol=tol, atol=1e-6)   # side-stream exchange schedule (SAGE)
+
+
+def _gat_layer_ab_main(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "occ-gnn_amd"))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cslicer import _abi, splitgnn
+        from test_gpu_train import _table, _task
+        indptr, indices, feats, labels, perm = _task()
+        dev = torch.device("cuda", 0)
+        eng = _abi.Engine(indptr, indices, n_parts=world, fanouts=(10, 5), max_batch=128, n_streams=1, mode=_abi.MODE_GRAPH,
+                          workload=_table(indptr.shape[0] - 1, world), part_mask=1 << rank)
+        eng.submit_seeds([perm[:128]])
+        slices = splitgnn.slices_of(eng, parts=[rank])
+        sl = slices[1][rank]                                          # the deepest layer's slice of this rank
+        torch.manual_seed(0)
+        model = splitgnn.DistGATModel(feats.shape[1], 16, 5, heads=2, n_layers=2).to(dev)
+        with torch.no_grad():
+            for conv in model.convs:
+                conv.bias.normal_(0, 0.1)
+        comm = splitgnn.DistComm(device=dev)
+        x0 = torch.from_numpy(feats).to(dev)[sl.in_nodes.long()]
+        w = torch.randn(slices[0][rank].n_owned, 5, generator=torch.Generator().manual_seed(rank)).to(dev)
+        res = []
+        for fused in (True, False):
+            splitgnn._GAT_RANK_AUTOGRAD = not fused
+            model.zero_grad()
+            x = x0.clone().requires_grad_()
+            out = model.forward_rank(slices, x, rank, comm)
+            (out * w).sum().backward()
+            res.append([out.detach().cpu().numpy(), x.grad.cpu().numpy()] + [p.grad.cpu().numpy() for p in model.parameters()])
+        eng.close()
+        dist.barrier()
+        q.put((rank, res))
+    except Exception as ex:
+        q.put((rank, "error: " + repr(ex)))
+        raise
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fused_gat_rank_layer_matches_its_autograd_form(world):
+    """aggr.GatLayerRank (a rank's whole DistGATConv layer as one autograd node: fused kernels, exchanges over the
+    back-to-back lists, the backward by hand) against the node-by-node form, a two-layer model on the same slices, ranks
+    over gloo on one GPU: output, input gradient and every parameter gradient of every rank."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gat_layer_ab_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t_: t_[0])
+    for p in procs:
+        p.join(timeout=120)
+    names = ["out", "grad x"] + ["grad %s of layer %d" % (n_, k) for k in range(2) for n_ in ("attn_l", "attn_r", "bias", "weight")]
+    for rank, r_ in res:
+        assert not isinstance(r_, str), r_
+        assert len(r_[0]) == len(names)
+        for name, a_, b_ in zip(names, r_[0], r_[1]):
+            # (a nearly empty rank's gradients are sums over a handful of rows: entries of 1e-8 are rounding noise)
+            scale = max(1e-1, float(np.abs(b_).max()))
+            np.testing.assert_allclose(a_, b_, rtol=1e-4, atol=1e-5 * scale, err_msg="rank %d %s" % (rank, name))
