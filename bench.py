@@ -691,30 +691,39 @@ def main():
 
     # ---- the same step DATA-parallel (several GPUs only): every GPU holds graph + features, trains 1/N of each minibatch
     # with the single-GPU native step, one gradient all-reduce per step (cslicer.train.DataParallelTrainer)
-    def e2e_dp_leg():
+    def e2e_dp_leg(kind="sage"):
+        """kind "gat": BASELINE config 5's model (8 heads x 32, fanout 10/10/10) data-parallel -- a rank's split-parallel GAT
+        step is launch-bound whatever its share, so this is the form in which the attention model uses
+        several GPUs of a node whose HBM holds graph + features"""
         from cslicer.train import DataParallelTrainer, synthetic_node_data
         feats = lambda own: synthetic_node_data(N, args.e2e_feat, args.e2e_classes, seed=0, rows=own)[0]  # noqa: E731
         labels = lambda own: synthetic_node_data(N, 1, args.e2e_classes, seed=0, rows=own)[1]            # noqa: E731
+        gat = kind == "gat"
+        dfan, dhid, dstreams, dsteps = ((10, 10, 10), 32, 32, args.e2e_gat_steps) if gat else (
+            fan, args.e2e_hidden, args.e2e_streams, args.e2e_steps)
         tr = DataParallelTrainer(indptr, indices, feats, labels, args.e2e_classes, rank, world, dist, batch=B,
-                                 fanouts=fan, streams=args.e2e_streams, hidden=args.e2e_hidden, device=device,
-                                 feat_dim=args.e2e_feat)
+                                 fanouts=dfan, streams=dstreams, hidden=dhid, device=device, feat_dim=args.e2e_feat,
+                                 model=kind, heads=8)
         tr.set_nodes(perm)
-        after = (48 + args.e2e_steps) % tr.n_batches
-        tr.run(48, then=(48, args.e2e_steps))
+        warm = 48 if not gat else 32
+        after = (warm + dsteps) % tr.n_batches
+        tr.run(warm, then=(warm, dsteps))
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        tr.run(args.e2e_steps, first_batch=48, then=(after, args.e2e_streams))   # (slices as many rounds as it trains)
+        tr.run(dsteps, first_batch=warm, then=(after, dstreams))   # (slices as many rounds as it trains)
         torch.cuda.synchronize()
         barrier()
         t_dp = shard.max_over_ranks(time.perf_counter() - t0, dist, red_dev)
         tr.close()
-        return {"iters_per_sec": args.e2e_steps / t_dp, "ms_per_iter": 1e3 * t_dp / args.e2e_steps,
-                "steps": args.e2e_steps, "scaling": "strong",
-                "config": "data-parallel GraphSAGE fanout %s, batch %d (global; %d seeds per GPU), %d GPU(s), whole graph + "
-                          "feature table on every GPU, native step + one gradient all-reduce per step; features %d, "
-                          "hidden %d, classes %d, fp32, Adam" % ("/".join(map(str, fan)), B, (B + world - 1) // world,
-                                                                 world, args.e2e_feat, args.e2e_hidden, args.e2e_classes)}
+        return {"iters_per_sec": dsteps / t_dp, "ms_per_iter": 1e3 * t_dp / dsteps,
+                "steps": dsteps, "scaling": "strong",
+                "config": "data-parallel %s fanout %s, batch %d (global; %d seeds per GPU), %d GPU(s), whole graph + "
+                          "feature table on every GPU, %s + one gradient all-reduce per step; features %d, "
+                          "hidden %d, classes %d, fp32, Adam" % (
+                              "GAT (8 heads)" if gat else "GraphSAGE", "/".join(map(str, dfan)), B, (B + world - 1) // world,
+                              world, "single-GPU attention step" if gat else "native step", args.e2e_feat, dhid,
+                              args.e2e_classes)}
 
     live_pmc_kernel = None
     if rank == 0:
@@ -893,6 +902,9 @@ def main():
                 partial.update(res)
                 if not args.no_e2e_dp and args.e2e_model == "sage":
                     res["data_parallel"] = e2e_dp_leg()
+                    partial.update(res)
+                    if args.e2e_gat_steps > 0:
+                        res["data_parallel_gat"] = e2e_dp_leg("gat")
                 return res
             run_guarded(both_legs, out, rank, world, args.e2e_timeout, default_store(dist), partial)
     finish(out, rank, dist)

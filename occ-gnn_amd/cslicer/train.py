@@ -216,7 +216,8 @@ class Trainer(object):
             else:
                 seeds = seeds.long()
                 y = self.labels[seeds if self.P == 1 else self.local_row[seeds].long()]
-                loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / max(n_seeds, 1)
+                den = max(n_seeds, 1) if self.rank_path else self._loss_den(stream, slot, n_seeds)   # (data-parallel: global)
+                loss = torch.nn.functional.cross_entropy(logits, y, reduction="sum") / den
             _roctx.pop()
         self.t_forward += time.perf_counter() - t1
         _roctx.push("backward")
@@ -232,6 +233,16 @@ class Trainer(object):
             _roctx.pop()
             _roctx.push("optimizer")
             self.opt.step(flat_grads=flat)                # the reduced buffer is used in place
+            _roctx.pop()
+        elif self.grad_sync is not None:
+            # data-parallel replicas on the autograd path (GAT): one all-reduce of the flat gradient, as the native step's
+            _roctx.push("grad_allreduce")
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                              for p in self.model.parameters()])
+            self.grad_sync(flat)
+            _roctx.pop()
+            _roctx.push("optimizer")
+            self.opt.step(flat_grads=flat)
             _roctx.pop()
         else:
             _roctx.push("optimizer")
@@ -357,7 +368,8 @@ class Trainer(object):
 class DataParallelTrainer(Trainer):
     """The same model trained DATA-parallel: every GPU holds the whole graph and feature table (288 GB of HBM per
     MI355X: ogbn-products is 1.5 GB, papers100M 64 GB), samples and trains its 1/W share of every minibatch with the
-    single-GPU native step, and one all-reduce (RCCL) sums the 0.7 MB of gradients.  Not the reference's design -- its
+    single-GPU native step (GraphSAGE; the attention model: the single-GPU autograd step with its fused layers), and one
+    all-reduce (RCCL) sums the 0.7 MB of gradients.  Not the reference's design -- its
     trainer is split-parallel (python/train.py, `Trainer` above with world > 1) -- but what the same slicer + step give
     when a GPU is large enough to hold everything: no per-layer boundary exchange, the only collective is the gradient
     all-reduce.  A minibatch of B seeds is dealt in contiguous chunks of ceil(B / W); the loss is the sum over a
@@ -372,9 +384,9 @@ class DataParallelTrainer(Trainer):
         kw.setdefault("rng_seed", 5489 + 7919 * self.dp_rank)
         super().__init__(indptr, indices, features, labels, n_classes, rank=0, world=1, batch=self.chunk, dist=None,
                          rank_path=False, **kw)
-        if self.native is None:
+        if self.native is None and self.kind != "gat":
             raise ValueError("the data-parallel trainer runs the native GraphSAGE step (feature and hidden widths "
-                             "multiples of 4, at least two layers)")
+                             "multiples of 4, at least two layers) or the single-GPU GAT step")
         if self.dp_world > 1:
             self.grad_sync = lambda flat: self.dp_dist.all_reduce(flat)
         self._den = {}

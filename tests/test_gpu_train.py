@@ -56,7 +56,7 @@ def test_native_step_trains_like_the_python_step(monkeypatch):
     np.testing.assert_allclose(curves[0], curves[1], rtol=2e-3)
 
 
-def _dp_rank_main(rank, world, port, q):
+def _dp_rank_main(rank, world, port, q, kind="sage"):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "occ-gnn_amd"))
@@ -71,7 +71,8 @@ def _dp_rank_main(rank, world, port, q):
         indptr, indices, feats, labels, perm = _task()
         # batch 250 over 3 ranks: chunks of 84 / 84 / 82; the epoch's last minibatch is short
         t = DataParallelTrainer(indptr, indices, feats, labels, 5, rank, world, dist, batch=250, fanouts=(10, 5),
-                                streams=3, hidden=16, lr=1e-2, seed=3)
+                                streams=3, hidden=16, lr=1e-2, seed=3, model=kind, heads=2)
+        assert (t.native is not None) == (kind == "sage")
         # the ranks' mt19937 streams differ (rank-dependent seed): the same seed list draws different neighbourhoods
         from cslicer import splitgnn
         t.eng.submit_seeds([perm[:64]], slot=0)
@@ -90,16 +91,16 @@ def _dp_rank_main(rank, world, port, q):
         raise
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_data_parallel_ranks_stay_identical_and_learn(world):
-    """DataParallelTrainer: every rank trains its chunk of each minibatch with the native step, gradients are summed
-    by one all-reduce (gloo here, two / three processes on the one GPU): the replicas' weights stay bit-identical and
-    the loss falls."""
+@pytest.mark.parametrize("world,kind", [(2, "sage"), (3, "sage"), (2, "gat")])
+def test_data_parallel_ranks_stay_identical_and_learn(world, kind):
+    """DataParallelTrainer: every rank trains its chunk of each minibatch with the native step (GraphSAGE) or the single-GPU
+    attention step, gradients are summed by one all-reduce (gloo here, two / three processes on the one GPU): the replicas'
+    weights stay bit-identical and the loss falls."""
     import torch.multiprocessing as mp
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_rank_main, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_dp_rank_main, args=(r, world, port, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
@@ -116,7 +117,8 @@ def test_data_parallel_ranks_stay_identical_and_learn(world):
     # step and reduction), so the trajectory is the same in every run; "learns" is read off windows of six steps of the
     # 24, not off single noisy minibatch losses
     losses = got[0][1]
-    assert all(np.isfinite(losses)) and np.mean(losses[-6:]) < 0.9 * np.mean(losses[:6]), losses
+    # (the attention model, 2 heads x 16, moves more slowly on this task: 1.678 -> 1.623 over the 24 steps)
+    assert all(np.isfinite(losses)) and np.mean(losses[-6:]) < (0.9 if kind == "sage" else 0.98) * np.mean(losses[:6]), losses
 
 
 def test_data_parallel_world_of_one_is_the_single_gpu_trainer():
