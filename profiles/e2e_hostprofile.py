@@ -31,8 +31,10 @@ if len(sys.argv) > 2 and sys.argv[2] == "rank":
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from cslicer.train import use_tuned_gemms  # noqa: E402
 use_tuned_gemms()
-t = Trainer(indptr, indices, feats, labels, 47, fanouts=(15, 10, 5), batch=1024, streams=32, hidden=256,
-            rank_path=dist is not None, dist=dist)
+gat = os.environ.get("HP_MODEL", "sage") == "gat"     # HP_MODEL=gat HP_BATCH=128: a rank's share of config 5 on 8 GPUs
+t = Trainer(indptr, indices, feats, labels, 47, fanouts=(10, 10, 10) if gat else (15, 10, 5),
+            batch=int(os.environ.get("HP_BATCH", "1024")), streams=32, hidden=32 if gat else 256,
+            model="gat" if gat else "sage", rank_path=dist is not None, dist=dist)
 t.set_nodes(np.random.default_rng(1).permutation(n))
 t.run(64)
 import time  # noqa: E402
