@@ -1696,7 +1696,7 @@ int csl_gat_logits_fwd_f32(const float* z, const float* attn_l, const float* att
 }
 
 int64_t csl_gat_logits_bwd_scratch(int64_t n, int32_t H, int32_t D) {
-  const long long rpb = rb_rows(n);
+  const long long rpb = gat_finish_rows(n);
   return 2 * ((n + rpb - 1) / rpb) * (int64_t)H * D;
 }
 
@@ -1712,7 +1712,7 @@ int csl_gat_logits_bwd_acc_f32(const float* z, const float* attn_l, const float*
   if (n < 0 || !g_attn_l || !g_attn_r || H < 1 || D < 4 || D % 4 != 0 || D > 256) return CSL_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   const int C = H * D;
-  const long long rpb = rb_rows(n);
+  const long long rpb = gat_finish_rows(n);   // (small layers: many small workgroups, as the epilogue's backward)
   const long long blocks = (n + rpb - 1) / rpb;
   if (blocks > 0) {
     if (!g_el || !g_er || !g_z || !scratch || !gat_args_ok(z, attn_l, attn_r, H, D) || !aligned16(g_z) ||
