@@ -47,19 +47,84 @@ struct PyBipartite {
   int gpu_id = -1;
 };
 
-struct PySample {
-  std::vector<std::vector<PyBipartite*>*> layers;
-  long in_nodes = 0, out_nodes = 0;  // pybipartite.cpp:57-62 (not exported there either)
-  ~PySample() {
+// A sample the consumer lets go of hands its BiPartites (a dozen objects, ~100 vectors, megabytes of `long`) to this
+// recycler instead of freeing them on the consumer's thread -- "the consumer's own deletes of the previous sample set the
+// pace" of the drop-in path in round 2 -- and the converter fills recycled ones: their vectors keep their capacity, so a
+// steady state neither allocates nor frees nor page-faults.  Bounded (the queue holds 10 samples, a few more are in flight);
+// what does not fit is freed as before.  CSLICER_NO_RECYCLE=1: A/B switch.
+class Recycler {
+ public:
+  typedef std::vector<std::vector<PyBipartite*>*> Layers;
+  static Recycler& get() {
+    static Recycler* r = new Recycler();   // (never destroyed: a sample may outlive every static object at interpreter exit)
+    return *r;
+  }
+  // true: taken over (the caller must not free them)
+  bool give(Layers& layers) {
+    if (off_ || layers.empty()) return false;
+    std::lock_guard<std::mutex> lk(m_);
+    if (free_.size() >= kMax) return false;
+    free_.emplace_back(std::move(layers));
+    layers.clear();
+    return true;
+  }
+  bool take(int n_layers, int n_parts, Layers* out) {
+    if (off_) return false;
+    std::lock_guard<std::mutex> lk(m_);
+    for (size_t i = free_.size(); i-- > 0;) {
+      Layers& c = free_[i];
+      if ((int)c.size() == n_layers && (int)c[0]->size() == n_parts && (int)(*c[0])[0]->from_ids.size() == n_parts) {
+        *out = std::move(c);
+        free_.erase(free_.begin() + (long)i);
+        return true;
+      }
+    }
+    return false;
+  }
+  static void destroy(Layers& layers) {
     for (auto l : layers) {
       for (auto b : *l) delete b;
       delete l;
     }
+    layers.clear();
+  }
+  ~Recycler() {
+    for (auto& c : free_) destroy(c);
+  }
+
+ private:
+  Recycler() : off_(getenv("CSLICER_NO_RECYCLE") != nullptr) {}
+  static constexpr size_t kMax = 24;
+  const bool off_;
+  std::mutex m_;
+  std::vector<Layers> free_;
+};
+
+struct PySample {
+  std::vector<std::vector<PyBipartite*>*> layers;
+  long in_nodes = 0, out_nodes = 0;  // pybipartite.cpp:57-62 (not exported there either)
+  ~PySample() {
+    if (!Recycler::get().give(layers)) Recycler::destroy(layers);
   }
 };
 
 PySample* empty_sample(int n_layers, int n_parts) {
   PySample* s = new PySample();
+  if (Recycler::get().take(n_layers, n_parts, &s->layers)) {
+    // recycled
+    for (int l = 0; l < n_layers; l++) {
+      for (int g = 0; g < n_parts; g++) {
+        PyBipartite* b = (*s->layers[l])[g];
+        b->gpu_id = g;
+        // (clear() keeps the capacity; the lists are Python-writable, so nothing of the previous sample may show through)
+        b->in_nodes.clear(), b->indptr.clear(), b->out_nodes.clear(), b->owned_out_nodes.clear(), b->indices.clear();
+        b->self_ids_in.clear(), b->self_ids_out.clear();
+        for (auto& v : b->from_ids) v.clear();
+        for (auto& v : b->to_ids) v.clear();
+      }
+    }
+    return s;
+  }
   for (int l = 0; l < n_layers; l++) {
     auto row = new std::vector<PyBipartite*>();
     for (int g = 0; g < n_parts; g++) {
