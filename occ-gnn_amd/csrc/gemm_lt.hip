@@ -210,11 +210,12 @@ int make_plan_impl(const Key& key, Plan& p, const float* A, const float* B, floa
     LT(a.LayoutSet(p.lb, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_second, sizeof(s_second)));
     LT(a.LayoutSet(p.lc, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &s_c, sizeof(s_c)));
   }
-  // The long dimension (the rows: m, or k of a weight gradient) is blanked to a SIZE BUCKET, not to nothing: 0 = 1024 rows
-  // and more (what the recorded plans were tuned on; the 1.9 k-row slabs of a batch-1024 weight gradient included), 1 = fewer.  With one class for every row count the 1 k-row layers
+  // The long dimension (the rows: m, or k of a weight gradient) is blanked to a SIZE BUCKET, not to nothing: 0 = 4096 rows
+  // and more (what the recorded plans were tuned on; for a weight gradient: slabs of 1024 rows and more, the 1.9 k-row slabs of
+  // a batch-1024 step included), 2 = 1024..4095 rows, 1 = fewer.  With one class for every row count the 1 k-row layers
   // -- the top layer of every model, every layer of a 128-seed rank or replica step -- ran the 128 x 192 tile kernel chosen
   // for 8 k rows on eight workgroups (28 us for 0.27 GFLOP: profiles/r3_rank/rank128_kernels.md).
-  const long long small = (transa ? k : m) < 1024 ? 1 : 0;
+  const long long small = transa ? (k < 1024 ? 1 : 0) : (m < 1024 ? 1 : (m < 4096 ? 2 : 0));
   const Key cls = transa ? Key(transa, transb, m, n, small, lda, ldb, ldc, batch, 0, 0, sc, epi)
                          : Key(transa, transb, small, n, k, lda, ldb, ldc, batch, 0, sb, 0, epi);
   {
@@ -419,7 +420,7 @@ int csl_gemm_f32(int32_t transa, int32_t transb, int64_t m, int64_t n, int64_t k
 }
 
 /* Recorded plans: one line per shape class, "ta tb m n k lda ldb ldc batch sa sb sc epilogue index" (the long dimension
- * is its size bucket -- 0: 1024 and more, 1: fewer --, the strides that follow it are 0), after a header naming the library version the solution indices belong to. */
+ * is its size bucket -- 0: 4096 rows and more (weight-gradient slabs: 1024 and more), 2: 1024..4095, 1: fewer --, the strides that follow it are 0), after a header naming the library version the solution indices belong to. */
 int csl_gemm_save_plans(const char* path) {
   std::lock_guard<std::mutex> lock(g.mu);
   if (!path || !g.handle || !g.api.ext()) return CSL_E_STATE;
