@@ -30,6 +30,7 @@ SYMBOLS = ["csl_spmm_sum_f32", "csl_spmm_sum_bwd_f32", "csl_gather_rows_f32",
            "csl_gat_in_proj_f32", "csl_gat_in_proj_bwd_scratch", "csl_gat_in_proj_bwd_f32", "csl_gat_in_layer_fwd_scratch",
            "csl_gat_in_layer_fwd_f32", "csl_gat_in_layer_bwd_scratch", "csl_gat_in_layer_bwd_f32"]
 _ready = False
+_GAT_TORCH_MM = bool(os.environ.get("CSLICER_GAT_TORCH_MM"))
 
 
 def _lib():
@@ -814,7 +815,10 @@ class GatLayerLocal(torch.autograd.Function):
                 xp[n_in:].zero_()
         else:
             xp = x
-        z = xp @ weight.t()                                         # [mp, H*D]
+        # (csl_gemm_f32: the algorithm is chosen by timing the library's candidates per shape class and size bucket; torch's
+        # matmul takes the library's first suggestion, which for the 8 k-row layers is a 256 x 256 tile kernel on 32
+        # workgroups: 44-68 us for ~1 GFLOP.  CSLICER_GAT_TORCH_MM=1: A/B switch)
+        z = xp @ weight.t() if _GAT_TORCH_MM else gemm(xp, _f32(weight), transb=True)      # [mp, H*D]
         al, ar, b = _f32(attn_l).contiguous(), _f32(attn_r).contiguous(), _f32(bias).contiguous()
         indptr, indices, self_ids_in = _i32(indptr), _i32(indices), _i32(self_ids_in)
         dev = x.device
@@ -895,7 +899,7 @@ class GatLayerLocal(torch.autograd.Function):
         gw = weight_grad(g_z, xp)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = g_z @ weight                        # rows behind n_in are zero (g_z's are)
+            gx = g_z @ weight if _GAT_TORCH_MM else gemm(g_z, weight)   # rows behind n_in are zero (g_z's are)
             if gx.shape[0] != ctx.x_rows:
                 gx = gx[:ctx.x_rows]
         return gx, gw, g_al, g_ar, g_bias, None, None, None, None, None, None, None, None, None, None, None, None, None
